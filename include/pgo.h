@@ -1,0 +1,260 @@
+/*
+ * pgo.h -- C-ABI of the MI355X-native 2D pose-graph backend (libpgo.so).
+ *
+ * This is the drop-in boundary for ONE path of wei-ght/toy-robust-backend-slam:
+ * DCS-ceres/main.cpp METHOD 0/1 (SE(2) odometry + loop-closure least squares,
+ * Dynamic Covariance Scaling, HuberLoss(0.01), Ceres LM).  Everything the
+ * reference does between `ceres::Problem problem;` (main.cpp:66) and the end of
+ * `ceres::Solve` (main.cpp:163) is replaced by pgo_create / pgo_solve /
+ * pgo_get_poses; the g2o loader, classifier, outlier injector and writers
+ * (include/g2o_util.h:23-186) are replaced by the pgo_g2o_* / pgo_inject_* /
+ * pgo_write_* host functions.  All citations are relative to /root/reference/DCS-ceres.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; the caller owns every host array it passes;
+ *     the library copies in at create and copies out on get.
+ *   - every function returns 0 on success or a negative pgo_status.
+ *     No exception crosses this boundary.
+ *   - a pgo_t handle is NOT thread-safe: one handle per host thread.
+ *   - functions marked [host] never touch the GPU and work on a GPU-less box;
+ *     functions marked [gpu] require a gfx950 device and fail with
+ *     PGO_ERR_NO_DEVICE otherwise (there is no CPU fallback on the product path).
+ */
+#ifndef PGO_H_
+#define PGO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+typedef enum pgo_status {
+  PGO_OK = 0,
+  PGO_ERR_INVALID_ARG = -1,   /* null pointer, bad size, bad index            */
+  PGO_ERR_IO = -2,            /* file cannot be opened / written              */
+  PGO_ERR_PARSE = -3,         /* malformed g2o record                         */
+  PGO_ERR_NO_DEVICE = -4,     /* no gfx950 device visible                     */
+  PGO_ERR_HIP = -5,           /* a HIP runtime call failed                    */
+  PGO_ERR_COMM = -6,          /* RCCL / shm communicator failure              */
+  PGO_ERR_NUMERIC = -7,       /* non-finite residual/Jacobian at the current point
+                                 (Ceres: "Residual and Jacobian evaluation failed") */
+  PGO_ERR_UNSUPPORTED = -8,   /* METHOD 2/3/4 etc.                            */
+  PGO_ERR_NOMEM = -9
+} pgo_status;
+
+const char* pgo_strerror(int status);           /* [host] static string           */
+const char* pgo_last_error(void);               /* [host] thread-local detail text */
+const char* pgo_version(void);                  /* [host]                          */
+
+/* edge kinds: include/g2o_util.h:14-16 */
+#define PGO_EDGE_ODOMETRY 0
+#define PGO_EDGE_CLOSURE 1
+#define PGO_EDGE_BOGUS 2
+
+/* ------------------------------------------------------ g2o graph (host side)
+ * Replaces class ReadG2O (include/g2o_util.h:20-188) + Node/Edge (include/graph.h).
+ * The graph is held as flat arrays; edges are stored in the reference's
+ * residual-block order: all odometry, then all closure, then all bogus
+ * (main.cpp:95-150).                                                          */
+typedef struct pgo_graph pgo_graph;
+
+/* ReadG2O::ReadG2O (g2o_util.h:23-89).  Same tags (VERTEX_SE2|VERTEX2,
+ * EDGE_SE2|EDGE2), same positional fields, same classifier: odometry iff
+ * abs(a-b) < 5 (g2o_util.h:68), endpoints addressed by vector position
+ * (g2o_util.h:70,77).  Unlike the reference, I/O and range errors are reported. */
+int pgo_g2o_load(const char* path, pgo_graph** out);                       /* [host] */
+/* same, from a memory buffer (used by tests and by the synthetic generator)      */
+int pgo_g2o_parse(const char* text, size_t len, pgo_graph** out);          /* [host] */
+/* build a graph directly from arrays (kind[] decides the three lists)            */
+int pgo_graph_from_arrays(int32_t n_poses, const double* poses_xyt,
+                          int32_t n_edges, const int32_t* ia, const int32_t* ib,
+                          const double* meas_xyt, const double* info6_or_null,
+                          const uint8_t* kind, pgo_graph** out);           /* [host] */
+void pgo_graph_free(pgo_graph* g);                                         /* [host] */
+
+int32_t pgo_graph_num_poses(const pgo_graph* g);
+int32_t pgo_graph_num_edges(const pgo_graph* g);            /* odo + closure + bogus */
+int32_t pgo_graph_num_edges_of_kind(const pgo_graph* g, int kind);
+/* borrowed pointers, valid until the graph is mutated or freed                    */
+const int32_t* pgo_graph_pose_ids(const pgo_graph* g);      /* Node::index          */
+double*        pgo_graph_poses(pgo_graph* g);               /* N x 3 (x,y,theta), mutable: Node::p */
+const int32_t* pgo_graph_edge_a(const pgo_graph* g);        /* position of Edge::a  */
+const int32_t* pgo_graph_edge_b(const pgo_graph* g);
+const double*  pgo_graph_edge_meas(const pgo_graph* g);     /* E x 3 (x,y,theta)    */
+const double*  pgo_graph_edge_info(const pgo_graph* g);     /* E x 6 I11 I12 I13 I22 I23 I33 (parsed, unused: SURVEY H5) */
+const uint8_t* pgo_graph_edge_kind(const pgo_graph* g);
+
+/* ReadG2O::add_random_C (g2o_util.h:151-171): `count` bogus loops drawn with the
+ * C library rand() in the reference's call order (a, b, m0, m1, m2), measurement
+ * rand()/RAND_MAX in INTEGER arithmetic, info (2,0,0,300,0,300).
+ * seed >= 0: srand(seed) first (reproducible);  seed < 0: srand(time(0)) as
+ * main.cpp:43 does.                                                              */
+int pgo_inject_outliers(pgo_graph* g, int32_t count, int64_t seed);        /* [host] */
+
+/* writePoseGraph_nodes / writePoseGraph_edges (g2o_util.h:93-112,179-186).
+ * precision <= 0 : the reference's default ostream formatting (6 significant
+ * digits); precision > 0 : that many significant digits (17 round-trips).        */
+int pgo_write_nodes(const pgo_graph* g, const char* path, int precision);  /* [host] */
+int pgo_write_edges(const pgo_graph* g, const char* path);                 /* [host] */
+/* g2o writer (VERTEX_SE2 / EDGE_SE2), for the synthetic configs                  */
+int pgo_write_g2o(const pgo_graph* g, const char* path);                   /* [host] */
+
+/* Synthetic Manhattan world (BASELINE configs C4/C5; the reference ships no
+ * generator -- spec in SURVEY.md section 8(d)): unit steps on the integer grid,
+ * +-90 degree turns with p=0.2, odometry noise N(0, 0.02 m / 0.01 rad), up to
+ * `max_loops_per_pose` closures to earlier poses (|i-j| >= 5) within 1.5 m until
+ * about edges_per_pose * N edges, initial poses = dead-reckoned odometry, plus
+ * round(outlier_frac * #closures) bogus loops with R4 semantics (uniform random
+ * endpoints, zero measurement).  PRNG: splitmix64(seed).                          */
+int pgo_synth_manhattan(int32_t n_poses, double edges_per_pose, double outlier_frac,
+                        uint64_t seed, pgo_graph** out);                   /* [host] */
+
+/* ------------------------------------------------------------ solver options
+ * Defaults (pgo_options_default) are the Ceres defaults the reference runs with
+ * (main.cpp:154-163 sets only progress + SPARSE_NORMAL_CHOLESKY) plus the
+ * constants hard-coded in the reference: Huber 0.01 (main.cpp:68), phi 0.5
+ * (src/ceres_error.cpp:185), fixed pose 0 (main.cpp:153).                        */
+typedef struct pgo_options {
+  int32_t method;              /* 0 = plain (OdometryResidue everywhere), 1 = DCS on closure+bogus (main.cpp:112-114,135-137) */
+  int32_t max_iters;           /* 50   Solver::Options::max_num_iterations        */
+  int32_t fixed_pose;          /* 0    position of the constant pose, -1 = none   */
+  int32_t jacobi_scaling;      /* 1                                               */
+  double  phi;                 /* 0.5  DCS upper bound                            */
+  double  huber_delta;         /* 0.01 ; <= 0 disables the loss                   */
+  double  ftol;                /* 1e-6  function_tolerance                        */
+  double  gtol;                /* 1e-10 gradient_tolerance (max-norm)             */
+  double  ptol;                /* 1e-8  parameter_tolerance                       */
+  double  radius0;             /* 1e4   initial_trust_region_radius               */
+  double  max_radius;          /* 1e16                                            */
+  double  min_radius;          /* 1e-32                                           */
+  double  min_relative_decrease; /* 1e-3                                          */
+  double  min_lm_diagonal;     /* 1e-6                                            */
+  double  max_lm_diagonal;     /* 1e32                                            */
+  /* linear solver: block-Jacobi preconditioned CG on (J'J + D'D) y = J'r        */
+  double  pcg_rtol;            /* stop when ||r|| <= pcg_rtol * ||b||  (1e-12: "exact" mode
+                                  standing in for SPARSE_NORMAL_CHOLESKY; 0.1 = Ceres' eta for inexact steps) */
+  int32_t pcg_max_iters;       /* cap per LM iteration                            */
+  int32_t pcg_check_every;     /* iterations enqueued between host residual checks */
+  int32_t verbose;             /* 1 = Ceres-like per-iteration table on stdout    */
+  int32_t use_graphs;          /* 1 = replay the CG iteration as a hipGraph       */
+  int32_t reserved[8];
+} pgo_options;
+
+void pgo_options_default(pgo_options* o);                                  /* [host] */
+
+typedef enum pgo_termination {
+  PGO_TERM_CONVERGENCE_FTOL = 1,
+  PGO_TERM_CONVERGENCE_GTOL = 2,
+  PGO_TERM_CONVERGENCE_PTOL = 3,
+  PGO_TERM_NO_CONVERGENCE = 4,       /* max_iters reached                        */
+  PGO_TERM_MIN_RADIUS = 5,
+  PGO_TERM_FAILURE = 6
+} pgo_termination;
+
+typedef struct pgo_iter_record {     /* one row of Ceres' progress table          */
+  int32_t iter;
+  int32_t step_ok;                   /* 1 accepted, 0 rejected, -1 invalid        */
+  double  cost;
+  double  cost_change;
+  double  gradient_max_norm;
+  double  step_norm;
+  double  relative_decrease;         /* tr_ratio                                  */
+  double  radius;
+  int32_t pcg_iters;
+  int32_t _pad;
+  double  pcg_rel_residual;
+  double  seconds;
+} pgo_iter_record;
+
+typedef struct pgo_summary {
+  int32_t termination;               /* pgo_termination                           */
+  int32_t iterations;                /* LM iterations performed (successful + not) */
+  int32_t successful_steps;
+  int32_t total_pcg_iters;
+  double  initial_cost;
+  double  final_cost;
+  double  seconds_total;
+  double  seconds_eval;              /* residual + Jacobian kernel                */
+  double  seconds_assemble;
+  double  seconds_linear;
+  double  seconds_candidate;
+} pgo_summary;
+
+/* ------------------------------------------------------------ communicator
+ * One process per GPU.  The graph is sharded by pose-id range over the ranks of
+ * a communicator; world == 1 needs no communicator (pass NULL to pgo_create).   */
+typedef struct pgo_comm pgo_comm;
+#define PGO_COMM_ID_BYTES 128
+int  pgo_comm_unique_id(uint8_t id[PGO_COMM_ID_BYTES]);        /* [gpu] ncclGetUniqueId on rank 0; broadcast by the caller */
+int  pgo_comm_create_rccl(const uint8_t id[PGO_COMM_ID_BYTES], int rank, int world, int device, pgo_comm** out); /* [gpu] */
+/* host-staged shared-memory communicator: TEST backend only (several ranks on one
+ * GPU, where RCCL refuses duplicate devices).  Same collectives, same results.   */
+int  pgo_comm_create_shm(const char* name, int rank, int world, int device, pgo_comm** out);                     /* [gpu] */
+void pgo_comm_destroy(pgo_comm* c);
+
+/* ------------------------------------------------------------------ solver
+ * pgo_create replaces main.cpp:66-68,95-153: it takes the whole graph (every
+ * rank passes the same arrays) and keeps the shard of `comm`'s rank on `device`. */
+typedef struct pgo_handle pgo_t;
+
+int pgo_create(pgo_t** h, int32_t n_poses, const double* poses_xyt,
+               int32_t n_edges, const int32_t* ia, const int32_t* ib,
+               const double* meas_xyt, const uint8_t* kind,
+               const pgo_options* opt, pgo_comm* comm_or_null, int device);       /* [gpu] */
+int pgo_create_from_graph(pgo_t** h, const pgo_graph* g, const pgo_options* opt,
+                          pgo_comm* comm_or_null, int device);                    /* [gpu] */
+void pgo_destroy(pgo_t* h);
+
+/* Problem::Evaluate equivalent.  poses_or_null == NULL evaluates at the handle's
+ * current poses.  r: E x 3, J: E x 18 = [d e/d P1 (3x3 row-major) | d e/d P2],
+ * both in the caller's edge order.  apply_loss != 0 applies the Huber corrector
+ * (r <- sqrt(rho') r, J <- sqrt(rho') J) as Ceres' ResidualBlock::Evaluate does.
+ * cost = 1/2 sum rho(|e|^2) (always with the loss when huber_delta > 0).
+ * r/J outputs need world == 1.                                                  */
+int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss,
+             double* cost, double* r_or_null, double* J_or_null);                 /* [gpu] */
+
+/* ceres::Solve (main.cpp:163): LM from the current poses for opt.max_iters.      */
+int pgo_solve(pgo_t* h, pgo_summary* s);                                          /* [gpu] */
+/* the same minimiser, resumable: (re)start with pgo_lm_begin, then run LM
+ * iterations in slices (bench.py times slices); returns *done != 0 once a
+ * termination test fired.                                                        */
+int pgo_lm_begin(pgo_t* h);                                                       /* [gpu] */
+int pgo_lm_step(pgo_t* h, int32_t n_iters, int32_t* done, pgo_summary* s);        /* [gpu] */
+int32_t pgo_num_iter_records(const pgo_t* h);
+int pgo_get_iter_records(const pgo_t* h, pgo_iter_record* out, int32_t cap);
+
+int pgo_get_poses(pgo_t* h, double* out_xyt /* N x 3 */);                         /* [gpu] */
+int pgo_set_poses(pgo_t* h, const double* poses_xyt);                             /* [gpu] */
+
+/* ------------------------------------------------ kernel-level entry points
+ * Used by the parity tests and by bench.py's roofline leg: each launches exactly
+ * one kind of kernel `reps` times on the handle's stream, brackets the launches
+ * with HIP events on that stream and returns the average milliseconds.          */
+typedef struct pgo_kernel_stats {
+  double ms_avg;              /* average launch duration (HIP events)            */
+  double algorithmic_bytes;   /* bytes one launch must move    */
+  int64_t units;              /* edges (K1/K2) or blocks (K3) per launch         */
+} pgo_kernel_stats;
+int pgo_bench_eval(pgo_t* h, int reps, int with_jacobian, pgo_kernel_stats* out); /* [gpu] K1 */
+int pgo_bench_assemble(pgo_t* h, int reps, pgo_kernel_stats* out);                /* [gpu] K2 */
+int pgo_bench_spmv(pgo_t* h, int reps, pgo_kernel_stats* out);                    /* [gpu] K3 */
+/* y = (J'J + D'D) x in the scaled space at the current linearisation, with the
+ * current LM diagonal; x,y: 3N doubles (world == 1).  For SpMV parity tests.    */
+int pgo_debug_spmv(pgo_t* h, const double* x, double* y);                         /* [gpu] */
+/* normal-equation pieces at the current point, caller's pose order (world == 1):
+ * g: 3N gradient J'r (unscaled), hdiag: N x 9 diagonal 3x3 blocks of J'J         */
+int pgo_debug_normal_eq(pgo_t* h, double* g_or_null, double* hdiag_or_null);      /* [gpu] */
+/* sharding plan of a graph over `world` ranks: for rank r, rows [lo, hi) and the
+ * number of local edges / cut edges.  Pure host logic.                           */
+int pgo_shard_plan(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
+                   int world, int rank, int32_t* lo, int32_t* hi,
+                   int32_t* n_local_edges, int32_t* n_cut_edges);                 /* [host] */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGO_H_ */

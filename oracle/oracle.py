@@ -1,0 +1,466 @@
+"""CPU oracle for the DCS pose-graph path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product path (libpgo.so + toy-robust-backend-slam_amd) never does.
+
+PARITY UNPINNED: the reference ships no tests / golden vectors for this path and
+cannot be built here (Ceres, Eigen3, Boost absent).  See oracle/pgo_oracle.c.
+
+Contents (paths relative to /root/reference/DCS-ceres):
+  read_g2o()        ReadG2O::ReadG2O            include/g2o_util.h:23-89
+  glibc_rand()      the C library rand() the reference's injector calls
+  add_random_C()    ReadG2O::add_random_C       include/g2o_util.h:151-171
+  evaluate()        residual blocks + Huber     src/ceres_error.cpp:42-94,135-196, main.cpp:66-68
+  lm_direct()       ceres::Solve, default options, SPARSE_NORMAL_CHOLESKY (main.cpp:154-163):
+                    Ceres 2.x TrustRegionMinimizer + LevenbergMarquardtStrategy policy with the
+                    linear system solved by a sparse direct factorisation (scipy SuperLU)
+  lm_pcg()          the same policy with block-Jacobi PCG, in C (pgo_oracle_lm_pcg): the "port"
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libpgo_oracle.so")
+    src = os.path.join(_HERE, "pgo_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpgo_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class _Opts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("method", "max_iters", "fixed_pose", "jacobi_scaling")] + \
+               [(n, C.c_double) for n in ("phi", "huber_delta", "ftol", "gtol", "ptol", "radius0", "max_radius",
+                                          "min_radius", "min_relative_decrease", "min_lm_diagonal",
+                                          "max_lm_diagonal", "pcg_rtol")] + \
+               [(n, C.c_int32) for n in ("pcg_max_iters", "threads", "verbose", "_pad")]
+
+
+class _Iter(C.Structure):
+    _fields_ = [("iter", C.c_int32), ("step_ok", C.c_int32)] + \
+               [(n, C.c_double) for n in ("cost", "cost_change", "gradient_max_norm", "step_norm",
+                                          "relative_decrease", "radius")] + \
+               [("pcg_iters", C.c_int32), ("_pad", C.c_int32), ("pcg_rel_residual", C.c_double),
+                ("seconds", C.c_double)]
+
+
+class _Summary(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("termination", "iterations", "successful_steps", "total_pcg_iters")] + \
+               [(n, C.c_double) for n in ("initial_cost", "final_cost", "seconds_total", "seconds_eval",
+                                          "seconds_assemble", "seconds_linear", "seconds_candidate")]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        dp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+        L.pgo_oracle_edge.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp]
+        L.pgo_oracle_edge.restype = None
+        L.pgo_oracle_huber.argtypes = [C.c_double, C.c_double, dp]
+        L.pgo_oracle_huber.restype = None
+        L.pgo_oracle_eval.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, C.c_int, C.c_double, C.c_double,
+                                      C.c_int, dp, dp, C.c_int]
+        L.pgo_oracle_eval.restype = C.c_double
+        L.pgo_oracle_lm_pcg.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, C.POINTER(_Opts), C.POINTER(_Iter),
+                                        C.c_int, C.POINTER(C.c_int), C.POINTER(_Summary)]
+        L.pgo_oracle_lm_pcg.restype = C.c_int
+        L.pgo_oracle_normal_eq.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, C.c_int, C.c_double, C.c_double,
+                                           C.c_int, dp, dp, dp, dp, dp, C.c_int]
+        L.pgo_oracle_normal_eq.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _bp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+# --------------------------------------------------------------------- graph
+@dataclass
+class Graph:
+    pose_id: np.ndarray          # int32 [N]
+    poses: np.ndarray            # float64 [N,3]
+    ia: np.ndarray               # int32 [E]  (positions, as the reference indexes nNodes[])
+    ib: np.ndarray
+    meas: np.ndarray             # float64 [E,3]
+    info: np.ndarray             # float64 [E,6]
+    kind: np.ndarray             # uint8 [E]  0 odometry, 1 closure, 2 bogus
+
+    @property
+    def n_poses(self):
+        return len(self.pose_id)
+
+    @property
+    def n_edges(self):
+        return len(self.ia)
+
+    def copy(self):
+        return Graph(*(np.array(getattr(self, f), copy=True) for f in
+                       ("pose_id", "poses", "ia", "ib", "meas", "info", "kind")))
+
+
+def read_g2o(path: str) -> Graph:
+    """include/g2o_util.h:23-89: split on single spaces (compressed), tags VERTEX_SE2|VERTEX2 and
+    EDGE_SE2|EDGE2, odometry iff abs(a-b) < 5, edge lists in file order: odometry then closure."""
+    ids, poses = [], []
+    groups = ([], [])
+    with open(path, "r") as f:
+        for line in f:
+            w = [t for t in line.rstrip("\n").split(" ")]
+            # boost::split with token_compress_on keeps one empty token at a leading space
+            if w and w[0] == "" and len(w) > 1:
+                continue
+            w = [t for t in w if t != ""]
+            if not w:
+                continue
+            if w[0] in ("VERTEX_SE2", "VERTEX2"):
+                ids.append(int(w[1]))
+                poses.append((float(w[2]), float(w[3]), float(w[4])))
+            elif w[0] in ("EDGE_SE2", "EDGE2"):
+                a, b = int(w[1]), int(w[2])
+                rec = (a, b) + tuple(float(t) for t in w[3:12])
+                groups[0 if abs(a - b) < 5 else 1].append(rec)
+    rows = groups[0] + groups[1]
+    arr = np.array(rows, dtype=np.float64).reshape(-1, 11)
+    kind = np.array([0] * len(groups[0]) + [1] * len(groups[1]), dtype=np.uint8)
+    return Graph(np.array(ids, np.int32), np.array(poses, np.float64).reshape(-1, 3),
+                 arr[:, 0].astype(np.int32), arr[:, 1].astype(np.int32),
+                 np.ascontiguousarray(arr[:, 2:5]), np.ascontiguousarray(arr[:, 5:11]), kind)
+
+
+class GlibcRand:
+    """glibc's rand()/srand() (TYPE_3 additive feedback generator, r[i] = r[i-3] + r[i-31]),
+    restated so that the injector's draws can be checked without calling the C library."""
+    RAND_MAX = 2147483647
+
+    def __init__(self, seed: int):
+        seed = seed & 0xFFFFFFFF
+        if seed == 0:
+            seed = 1
+        r = [0] * 34
+        r[0] = seed
+        for i in range(1, 31):
+            # 16807 * r[i-1] % 2147483647 computed with Schrage's trick on signed 32-bit words
+            word = r[i - 1] if r[i - 1] < 2 ** 31 else r[i - 1] - 2 ** 32
+            hi, lo = int(word / 127773), 0
+            hi = word // 127773 if word >= 0 else -((-word) // 127773)
+            lo = word - hi * 127773
+            word = 16807 * lo - 2836 * hi
+            if word < 0:
+                word += 2147483647
+            r[i] = word
+        for i in range(31, 34):
+            r[i] = r[i - 31]
+        self.r = r
+        for _ in range(34, 344):
+            self._step()
+
+    def _step(self):
+        r = self.r
+        v = (r[-31] + r[-3]) & 0xFFFFFFFF
+        r.append(v)
+        if len(r) > 64:
+            del r[:len(r) - 34]
+        return v
+
+    def rand(self) -> int:
+        return self._step() >> 1
+
+
+def add_random_C(g: Graph, count: int, seed: int) -> Graph:
+    """include/g2o_util.h:151-171 with srand(seed): a, b, then three rand()/RAND_MAX integer divisions."""
+    rng = GlibcRand(seed)
+    n = g.n_poses
+    ia, ib, meas = [], [], []
+    for _ in range(count):
+        a = rng.rand() % n
+        b = rng.rand() % n
+        if a == b:
+            b = (b + 1) % n
+        m = [float(rng.rand() // GlibcRand.RAND_MAX) for _ in range(3)]
+        ia.append(a)
+        ib.append(b)
+        meas.append(m)
+    out = g.copy()
+    if count:
+        out.ia = np.concatenate([g.ia, np.array(ia, np.int32)])
+        out.ib = np.concatenate([g.ib, np.array(ib, np.int32)])
+        out.meas = np.concatenate([g.meas, np.array(meas, np.float64).reshape(-1, 3)])
+        out.info = np.concatenate([g.info, np.tile(np.array([2.0, 0, 0, 300.0, 0, 300.0]), (count, 1))])
+        out.kind = np.concatenate([g.kind, np.full(count, 2, np.uint8)])
+    return out
+
+
+# ---------------------------------------------------------------- evaluation
+def edge(P1, P2, meas, dcs: bool, phi: float = 0.5, jac: bool = True):
+    P1 = np.ascontiguousarray(P1, np.float64)
+    P2 = np.ascontiguousarray(P2, np.float64)
+    m = np.ascontiguousarray(meas, np.float64)
+    e = np.zeros(3)
+    J = np.zeros(18) if jac else None
+    lib().pgo_oracle_edge(_dp(P1), _dp(P2), _dp(m), int(dcs), phi, _dp(e), _dp(J))
+    return (e, J.reshape(3, 6)) if jac else e
+
+
+def huber(s: float, delta: float = 0.01):
+    rho = np.zeros(3)
+    lib().pgo_oracle_huber(s, delta, _dp(rho))
+    return rho
+
+
+def evaluate(g: Graph, poses=None, method: int = 1, phi: float = 0.5, delta: float = 0.01, apply_loss: bool = True,
+             want_r: bool = True, want_J: bool = True, threads: int = 1):
+    poses = np.ascontiguousarray(g.poses if poses is None else poses, np.float64)
+    E = g.n_edges
+    r = np.zeros((E, 3)) if want_r else None
+    J = np.zeros((E, 18)) if want_J else None
+    ia, ib = np.ascontiguousarray(g.ia, np.int32), np.ascontiguousarray(g.ib, np.int32)
+    meas, kind = np.ascontiguousarray(g.meas, np.float64), np.ascontiguousarray(g.kind, np.uint8)
+    cost = lib().pgo_oracle_eval(g.n_poses, _dp(poses), E, _ip(ia), _ip(ib), _dp(meas), _bp(kind), method, phi, delta,
+                                 int(apply_loss), _dp(r), _dp(J), threads)
+    return cost, r, J
+
+
+def normal_eq(g: Graph, poses=None, method=1, phi=0.5, delta=0.01, fixed_pose=0, s=None, x=None, threads=1):
+    """(gradient S J'r, diagonal blocks of (JS)'(JS), optional y = (JS)'(JS) x) at `poses`."""
+    poses = np.ascontiguousarray(g.poses if poses is None else poses, np.float64)
+    N = g.n_poses
+    gout, hd = np.zeros(3 * N), np.zeros((N, 9))
+    y = np.zeros(3 * N) if x is not None else None
+    xs = np.ascontiguousarray(x, np.float64) if x is not None else None
+    ss = np.ascontiguousarray(s, np.float64) if s is not None else None
+    ia, ib = np.ascontiguousarray(g.ia, np.int32), np.ascontiguousarray(g.ib, np.int32)
+    meas, kind = np.ascontiguousarray(g.meas, np.float64), np.ascontiguousarray(g.kind, np.uint8)
+    lib().pgo_oracle_normal_eq(N, _dp(poses), g.n_edges, _ip(ia), _ip(ib), _dp(meas), _bp(kind), method, phi, delta,
+                               fixed_pose, _dp(ss), _dp(gout), _dp(hd), _dp(xs), _dp(y), threads)
+    return gout, hd, y
+
+
+# ------------------------------------------------------------------ LM policy
+@dataclass
+class Options:
+    method: int = 1
+    max_iters: int = 50
+    fixed_pose: int = 0
+    jacobi_scaling: int = 1
+    phi: float = 0.5
+    huber_delta: float = 0.01
+    ftol: float = 1e-6
+    gtol: float = 1e-10
+    ptol: float = 1e-8
+    radius0: float = 1e4
+    max_radius: float = 1e16
+    min_radius: float = 1e-32
+    min_relative_decrease: float = 1e-3
+    min_lm_diagonal: float = 1e-6
+    max_lm_diagonal: float = 1e32
+    pcg_rtol: float = 1e-12
+    pcg_max_iters: int = 100000
+    threads: int = 1
+    verbose: int = 0
+
+
+@dataclass
+class Result:
+    poses: np.ndarray
+    termination: int
+    iterations: int
+    successful_steps: int
+    initial_cost: float
+    final_cost: float
+    records: list = field(default_factory=list)
+    seconds: dict = field(default_factory=dict)
+    total_pcg_iters: int = 0
+
+
+TERM = {1: "CONVERGENCE_FTOL", 2: "CONVERGENCE_GTOL", 3: "CONVERGENCE_PTOL", 4: "NO_CONVERGENCE", 5: "MIN_RADIUS",
+        6: "FAILURE"}
+
+
+def lm_direct(g: Graph, opt: Options = Options()) -> Result:
+    """Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy, defaults of main.cpp:154-163, with the
+    normal equations (J'J + D'D) y = J'r solved by a sparse direct factorisation."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    N, E = g.n_poses, g.n_edges
+    x = np.array(g.poses, np.float64, copy=True)
+    fixed = opt.fixed_pose
+    free = np.ones(3 * N, bool)
+    if fixed >= 0:
+        free[3 * fixed:3 * fixed + 3] = False
+    free_idx = np.nonzero(free)[0]
+    col_of = -np.ones(3 * N, np.int64)
+    col_of[free_idx] = np.arange(len(free_idx))
+    # sparse pattern of J (3E x 3N): rows 3e+i, cols 3*ia+k / 3*ib+k
+    rows = np.repeat(np.arange(3 * E).reshape(E, 3), 6, axis=1).reshape(-1)
+    cols = np.concatenate([3 * g.ia[:, None] + np.arange(3), 3 * g.ib[:, None] + np.arange(3)], axis=1)
+    cols = np.tile(cols, (1, 3)).reshape(-1).astype(np.int64)
+
+    def jac_matrix(J):
+        A = sp.csr_matrix((J.reshape(-1), (rows, cols)), shape=(3 * E, 3 * N))
+        return A[:, free_idx].tocsc()
+
+    def ev(p, with_j):
+        return evaluate(g, p, opt.method, opt.phi, opt.huber_delta, True, with_j, with_j, opt.threads)
+
+    t_start = time.perf_counter()
+    tm = dict(eval=0.0, linear=0.0, candidate=0.0)
+    t0 = time.perf_counter()
+    cost, r, J = ev(x, True)
+    tm["eval"] += time.perf_counter() - t0
+    res = Result(x, 4, 0, 0, cost, cost)
+    if not np.isfinite(cost):
+        res.termination = 6
+        return res
+    A = jac_matrix(J)
+    rvec = r.reshape(-1)
+    if opt.jacobi_scaling:
+        s = 1.0 / (1.0 + np.sqrt(np.asarray(A.multiply(A).sum(axis=0)).reshape(-1)))
+    else:
+        s = np.ones(A.shape[1])
+    grad = A.T @ rvec
+    gmax = float(np.max(np.abs(grad))) if len(grad) else 0.0
+    x_norm = float(np.linalg.norm(x.reshape(-1)[free_idx]))
+    radius, dec = opt.radius0, 2.0
+    prev_success, invalid_run = True, 0
+    recs = [dict(iter=0, step_ok=1, cost=cost, cost_change=0.0, gradient_max_norm=gmax, step_norm=0.0,
+                 relative_decrease=0.0, radius=radius)]
+    it = 0
+    term = 4
+    while True:
+        it += 1
+        if it > opt.max_iters:
+            term = 4
+            it -= 1
+            break
+        if prev_success and gmax <= opt.gtol:
+            term = 2
+            it -= 1
+            break
+        if radius < opt.min_radius:
+            term = 5
+            it -= 1
+            break
+        As = A @ sp.diags(s)
+        H = (As.T @ As).tocsc()
+        diag = np.clip(H.diagonal(), opt.min_lm_diagonal, opt.max_lm_diagonal)
+        D2 = diag / radius
+        gs = s * grad
+        t0 = time.perf_counter()
+        y = spla.splu((H + sp.diags(D2)).tocsc()).solve(gs)
+        tm["linear"] += time.perf_counter() - t0
+        m = As @ (-y)
+        model = float(-m @ (rvec + 0.5 * m))
+        rec = dict(iter=it, step_ok=0, cost=cost, cost_change=0.0, gradient_max_norm=gmax, step_norm=0.0,
+                   relative_decrease=0.0, radius=radius)
+        if not np.all(np.isfinite(y)) or not (model > 0.0):
+            invalid_run += 1
+            if invalid_run >= 5:
+                term = 6
+                break
+            radius /= dec
+            dec *= 2.0
+            prev_success = False
+            rec.update(step_ok=-1, radius=radius)
+            recs.append(rec)
+            continue
+        invalid_run = 0
+        delta = np.zeros(3 * N)
+        delta[free_idx] = -s * y
+        cand = x + delta.reshape(N, 3)
+        t0 = time.perf_counter()
+        cand_cost, _, _ = ev(cand, False)
+        tm["candidate"] += time.perf_counter() - t0
+        if not np.isfinite(cand_cost):
+            cand_cost = np.finfo(np.float64).max
+        step_norm = float(np.linalg.norm(delta))
+        cost_change = cost - cand_cost
+        rec.update(step_norm=step_norm, cost_change=cost_change)
+        if step_norm <= opt.ptol * (x_norm + opt.ptol):
+            term = 3
+            recs.append(rec)
+            break
+        if abs(cost_change) <= opt.ftol * cost:
+            term = 1
+            recs.append(rec)
+            break
+        rho = cost_change / model if cand_cost < np.finfo(np.float64).max else -np.inf
+        rec.update(relative_decrease=rho)
+        if rho > opt.min_relative_decrease:
+            x = cand
+            x_norm = float(np.linalg.norm(x.reshape(-1)[free_idx]))
+            t0 = time.perf_counter()
+            cost, r, J = ev(x, True)
+            tm["eval"] += time.perf_counter() - t0
+            if not np.isfinite(cost):
+                term = 6
+                break
+            A = jac_matrix(J)
+            rvec = r.reshape(-1)
+            grad = A.T @ rvec
+            gmax = float(np.max(np.abs(grad)))
+            radius = min(opt.max_radius, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3))
+            dec = 2.0
+            prev_success = True
+            res.successful_steps += 1
+            rec.update(step_ok=1, cost=cost, gradient_max_norm=gmax)
+        else:
+            radius /= dec
+            dec *= 2.0
+            prev_success = False
+            rec.update(step_ok=0, cost=cand_cost)
+        rec.update(radius=radius)
+        recs.append(rec)
+        if opt.verbose:
+            print("%4d % .6e % .2e % .2e % .2e % .2e % .2e" % (it, rec["cost"], cost_change, gmax, step_norm, rho,
+                                                               radius))
+    res.poses = x
+    res.termination = term
+    res.iterations = it
+    res.final_cost = cost
+    res.records = recs
+    tm["total"] = time.perf_counter() - t_start
+    res.seconds = tm
+    return res
+
+
+def lm_pcg(g: Graph, opt: Options = Options()) -> Result:
+    """Same LM policy, linear solve by block-Jacobi PCG, all in C (OpenMP): the CPU "port"."""
+    o = _Opts(opt.method, opt.max_iters, opt.fixed_pose, opt.jacobi_scaling, opt.phi, opt.huber_delta, opt.ftol,
+              opt.gtol, opt.ptol, opt.radius0, opt.max_radius, opt.min_radius, opt.min_relative_decrease,
+              opt.min_lm_diagonal, opt.max_lm_diagonal, opt.pcg_rtol, opt.pcg_max_iters, opt.threads, opt.verbose, 0)
+    cap = opt.max_iters + 2
+    recs = (_Iter * cap)()
+    nrec = C.c_int(0)
+    summ = _Summary()
+    x = np.array(g.poses, np.float64, copy=True)
+    ia, ib = np.ascontiguousarray(g.ia, np.int32), np.ascontiguousarray(g.ib, np.int32)
+    meas, kind = np.ascontiguousarray(g.meas, np.float64), np.ascontiguousarray(g.kind, np.uint8)
+    lib().pgo_oracle_lm_pcg(g.n_poses, _dp(x), g.n_edges, _ip(ia), _ip(ib), _dp(meas), _bp(kind), C.byref(o), recs, cap,
+                            C.byref(nrec), C.byref(summ))
+    out = Result(x, summ.termination, summ.iterations, summ.successful_steps, summ.initial_cost, summ.final_cost)
+    out.total_pcg_iters = summ.total_pcg_iters
+    out.records = [{f[0]: getattr(recs[i], f[0]) for f in _Iter._fields_ if f[0] != "_pad"} for i in range(nrec.value)]
+    out.seconds = dict(total=summ.seconds_total, eval=summ.seconds_eval, assemble=summ.seconds_assemble,
+                       linear=summ.seconds_linear, candidate=summ.seconds_candidate)
+    return out

@@ -1,0 +1,435 @@
+"""toy-robust-backend-slam_amd: MI355X-native 2D pose-graph backend (DCS path of
+wei-ght/toy-robust-backend-slam), Python binding over the C-ABI in include/pgo.h.
+
+This module is a thin ctypes layer: all computation happens in libpgo.so (hand-written HIP
+kernels for gfx950).  There is no CPU fallback -- solver entry points raise PgoError when no
+gfx950 device is visible or the library is missing.
+
+Names follow the reference (DCS-ceres/include/g2o_util.h, main.cpp):
+    ReadG2O(path)            load + classify a g2o file            g2o_util.h:23-89
+    .add_random_C(n, seed)   inject bogus loops                    g2o_util.h:151-171
+    .writePoseGraph_nodes / .writePoseGraph_edges                  g2o_util.h:93-112
+    Solver(graph, options)   problem assembly + ceres::Solve       main.cpp:66-163
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+__all__ = ["PgoError", "Options", "Summary", "IterRecord", "ReadG2O", "Graph", "Solver", "Comm", "lib", "build",
+           "synth_manhattan", "shard_plan", "KernelStats", "EXPORTS", "TERMINATION"]
+
+EDGE_ODOMETRY, EDGE_CLOSURE, EDGE_BOGUS = 0, 1, 2
+TERMINATION = {1: "CONVERGENCE_FTOL", 2: "CONVERGENCE_GTOL", 3: "CONVERGENCE_PTOL", 4: "NO_CONVERGENCE",
+               5: "MIN_RADIUS", 6: "FAILURE", 0: "RUNNING"}
+
+# every symbol include/pgo.h declares (tests check the library exports each one)
+EXPORTS = [
+    "pgo_strerror", "pgo_last_error", "pgo_version",
+    "pgo_g2o_load", "pgo_g2o_parse", "pgo_graph_from_arrays", "pgo_graph_free",
+    "pgo_graph_num_poses", "pgo_graph_num_edges", "pgo_graph_num_edges_of_kind", "pgo_graph_pose_ids",
+    "pgo_graph_poses", "pgo_graph_edge_a", "pgo_graph_edge_b", "pgo_graph_edge_meas", "pgo_graph_edge_info",
+    "pgo_graph_edge_kind", "pgo_inject_outliers", "pgo_write_nodes", "pgo_write_edges", "pgo_write_g2o",
+    "pgo_synth_manhattan", "pgo_options_default",
+    "pgo_comm_unique_id", "pgo_comm_create_rccl", "pgo_comm_create_shm", "pgo_comm_destroy",
+    "pgo_create", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_solve", "pgo_lm_begin", "pgo_lm_step",
+    "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses",
+    "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_debug_spmv", "pgo_debug_normal_eq",
+    "pgo_shard_plan",
+]
+
+
+class PgoError(RuntimeError):
+    def __init__(self, status: int, detail: str):
+        self.status = status
+        super().__init__(f"pgo status {status}: {detail}")
+
+
+class Options(C.Structure):
+    """mirror of pgo_options (include/pgo.h)"""
+    _fields_ = [("method", C.c_int32), ("max_iters", C.c_int32), ("fixed_pose", C.c_int32),
+                ("jacobi_scaling", C.c_int32),
+                ("phi", C.c_double), ("huber_delta", C.c_double), ("ftol", C.c_double), ("gtol", C.c_double),
+                ("ptol", C.c_double), ("radius0", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+                ("max_lm_diagonal", C.c_double), ("pcg_rtol", C.c_double),
+                ("pcg_max_iters", C.c_int32), ("pcg_check_every", C.c_int32), ("verbose", C.c_int32),
+                ("use_graphs", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().pgo_options_default(C.byref(self))
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(self, k, v)
+
+
+class IterRecord(C.Structure):
+    _fields_ = [("iter", C.c_int32), ("step_ok", C.c_int32), ("cost", C.c_double), ("cost_change", C.c_double),
+                ("gradient_max_norm", C.c_double), ("step_norm", C.c_double), ("relative_decrease", C.c_double),
+                ("radius", C.c_double), ("pcg_iters", C.c_int32), ("_pad", C.c_int32),
+                ("pcg_rel_residual", C.c_double), ("seconds", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "_pad"}
+
+
+class Summary(C.Structure):
+    _fields_ = [("termination", C.c_int32), ("iterations", C.c_int32), ("successful_steps", C.c_int32),
+                ("total_pcg_iters", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("seconds_total", C.c_double), ("seconds_eval", C.c_double), ("seconds_assemble", C.c_double),
+                ("seconds_linear", C.c_double), ("seconds_candidate", C.c_double)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["termination_name"] = TERMINATION.get(self.termination, "?")
+        return d
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("ms_avg", C.c_double), ("algorithmic_bytes", C.c_double), ("units", C.c_int64)]
+
+
+_LIB = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    return _build.build_lib(force=force, verbose=verbose)
+
+
+def lib():
+    """Load libpgo.so (building it first if the sources are newer).  Fails loudly."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if _build.needs_build():
+        try:
+            path = _build.build_lib()
+        except Exception as e:  # stale-but-present library is still usable on a box without hipcc
+            if not os.path.exists(path):
+                raise ImportError(f"libpgo.so is missing and could not be built: {e}") from e
+    L = C.CDLL(path)
+    vp, dp, ip, bp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    L.pgo_strerror.restype = C.c_char_p
+    L.pgo_strerror.argtypes = [C.c_int]
+    L.pgo_last_error.restype = C.c_char_p
+    L.pgo_version.restype = C.c_char_p
+    L.pgo_g2o_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.pgo_g2o_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    L.pgo_graph_from_arrays.argtypes = [C.c_int32, dp, C.c_int32, ip, ip, dp, dp, bp, C.POINTER(vp)]
+    L.pgo_graph_free.argtypes = [vp]
+    L.pgo_graph_free.restype = None
+    for f in ("pgo_graph_num_poses", "pgo_graph_num_edges"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = C.c_int32
+    L.pgo_graph_num_edges_of_kind.argtypes = [vp, C.c_int]
+    L.pgo_graph_num_edges_of_kind.restype = C.c_int32
+    for f, rt in (("pgo_graph_pose_ids", ip), ("pgo_graph_poses", dp), ("pgo_graph_edge_a", ip),
+                  ("pgo_graph_edge_b", ip), ("pgo_graph_edge_meas", dp), ("pgo_graph_edge_info", dp),
+                  ("pgo_graph_edge_kind", bp)):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = rt
+    L.pgo_inject_outliers.argtypes = [vp, C.c_int32, C.c_int64]
+    L.pgo_write_nodes.argtypes = [vp, C.c_char_p, C.c_int]
+    L.pgo_write_edges.argtypes = [vp, C.c_char_p]
+    L.pgo_write_g2o.argtypes = [vp, C.c_char_p]
+    L.pgo_synth_manhattan.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_uint64, C.POINTER(vp)]
+    L.pgo_options_default.argtypes = [C.POINTER(Options)]
+    L.pgo_options_default.restype = None
+    L.pgo_comm_unique_id.argtypes = [bp]
+    L.pgo_comm_create_rccl.argtypes = [bp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.pgo_comm_create_shm.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.pgo_comm_destroy.argtypes = [vp]
+    L.pgo_comm_destroy.restype = None
+    L.pgo_create.argtypes = [C.POINTER(vp), C.c_int32, dp, C.c_int32, ip, ip, dp, bp, C.POINTER(Options), vp, C.c_int]
+    L.pgo_create_from_graph.argtypes = [C.POINTER(vp), vp, C.POINTER(Options), vp, C.c_int]
+    L.pgo_destroy.argtypes = [vp]
+    L.pgo_destroy.restype = None
+    L.pgo_eval.argtypes = [vp, dp, C.c_int, dp, dp, dp]
+    L.pgo_solve.argtypes = [vp, C.POINTER(Summary)]
+    L.pgo_lm_begin.argtypes = [vp]
+    L.pgo_lm_step.argtypes = [vp, C.c_int32, ip, C.POINTER(Summary)]
+    L.pgo_num_iter_records.argtypes = [vp]
+    L.pgo_num_iter_records.restype = C.c_int32
+    L.pgo_get_iter_records.argtypes = [vp, C.POINTER(IterRecord), C.c_int32]
+    L.pgo_get_poses.argtypes = [vp, dp]
+    L.pgo_set_poses.argtypes = [vp, dp]
+    L.pgo_bench_eval.argtypes = [vp, C.c_int, C.c_int, C.POINTER(KernelStats)]
+    L.pgo_bench_assemble.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
+    L.pgo_bench_spmv.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
+    L.pgo_debug_spmv.argtypes = [vp, dp, dp]
+    L.pgo_debug_normal_eq.argtypes = [vp, dp, dp]
+    L.pgo_shard_plan.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, ip, ip, ip, ip]
+    _LIB = L
+    return L
+
+
+def _check(status: int):
+    if status != 0:
+        L = lib()
+        detail = (L.pgo_last_error() or b"").decode() or (L.pgo_strerror(status) or b"").decode()
+        raise PgoError(status, detail)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _bp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+class Graph:
+    """Host-side pose graph (owns a pgo_graph*).  Arrays are exposed as numpy views."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().pgo_graph_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- constructors
+    @classmethod
+    def load(cls, path: str) -> "Graph":
+        h = C.c_void_p()
+        _check(lib().pgo_g2o_load(os.fsencode(path), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def parse(cls, text) -> "Graph":
+        if isinstance(text, str):
+            text = text.encode()
+        h = C.c_void_p()
+        _check(lib().pgo_g2o_parse(text, len(text), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, poses, ia, ib, meas, kind, info=None) -> "Graph":
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 3)
+        ia = np.ascontiguousarray(ia, np.int32)
+        ib = np.ascontiguousarray(ib, np.int32)
+        meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 3)
+        kind = np.ascontiguousarray(kind, np.uint8)
+        info_a = np.ascontiguousarray(info, np.float64).reshape(-1, 6) if info is not None else None
+        h = C.c_void_p()
+        _check(lib().pgo_graph_from_arrays(len(poses), _dp(poses), len(ia), _ip(ia), _ip(ib), _dp(meas), _dp(info_a),
+                                           _bp(kind), C.byref(h)))
+        return cls(h)
+
+    # ---- sizes (reference: cout lines at main.cpp:60-63)
+    @property
+    def n_poses(self) -> int:
+        return lib().pgo_graph_num_poses(self._h)
+
+    @property
+    def n_edges(self) -> int:
+        return lib().pgo_graph_num_edges(self._h)
+
+    def n_edges_of_kind(self, kind: int) -> int:
+        return lib().pgo_graph_num_edges_of_kind(self._h, kind)
+
+    def _view(self, fn, shape, dtype):
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, dtype)
+        ptr = fn(self._h)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape)
+
+    @property
+    def pose_ids(self):
+        return self._view(lib().pgo_graph_pose_ids, (self.n_poses,), np.int32)
+
+    @property
+    def poses(self):  # mutable view: Node::p
+        return self._view(lib().pgo_graph_poses, (self.n_poses, 3), np.float64)
+
+    @property
+    def ia(self):
+        return self._view(lib().pgo_graph_edge_a, (self.n_edges,), np.int32)
+
+    @property
+    def ib(self):
+        return self._view(lib().pgo_graph_edge_b, (self.n_edges,), np.int32)
+
+    @property
+    def meas(self):
+        return self._view(lib().pgo_graph_edge_meas, (self.n_edges, 3), np.float64)
+
+    @property
+    def info(self):
+        return self._view(lib().pgo_graph_edge_info, (self.n_edges, 6), np.float64)
+
+    @property
+    def kind(self):
+        return self._view(lib().pgo_graph_edge_kind, (self.n_edges,), np.uint8)
+
+    # ---- reference-named operations
+    def add_random_C(self, count: int, seed: int = -1):
+        _check(lib().pgo_inject_outliers(self._h, count, seed))
+
+    def writePoseGraph_nodes(self, path: str, precision: int = 0):
+        _check(lib().pgo_write_nodes(self._h, os.fsencode(path), precision))
+
+    def writePoseGraph_edges(self, path: str):
+        _check(lib().pgo_write_edges(self._h, os.fsencode(path)))
+
+    def write_g2o(self, path: str):
+        _check(lib().pgo_write_g2o(self._h, os.fsencode(path)))
+
+
+def ReadG2O(path: str) -> Graph:
+    """ReadG2O g2o_manager(path) -- reference main.cpp:49"""
+    return Graph.load(path)
+
+
+def synth_manhattan(n_poses: int, edges_per_pose: float = 4.0, outlier_frac: float = 0.10,
+                    seed: int = 20260410) -> Graph:
+    h = C.c_void_p()
+    _check(lib().pgo_synth_manhattan(n_poses, edges_per_pose, outlier_frac, seed, C.byref(h)))
+    return Graph(h)
+
+
+def shard_plan(n_poses, ia, ib, world, rank):
+    ia = np.ascontiguousarray(ia, np.int32)
+    ib = np.ascontiguousarray(ib, np.int32)
+    lo, hi, nl, nc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib().pgo_shard_plan(n_poses, len(ia), _ip(ia), _ip(ib), world, rank, C.byref(lo), C.byref(hi),
+                                C.byref(nl), C.byref(nc)))
+    return lo.value, hi.value, nl.value, nc.value
+
+
+class Comm:
+    """One process per GPU.  kind='rccl' (production) or 'shm' (test backend, several ranks per GPU)."""
+
+    def __init__(self, handle, rank, world):
+        self._h, self.rank, self.world = handle, rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _check(lib().pgo_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, uid: bytes, rank: int, world: int, device: int) -> "Comm":
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        h = C.c_void_p()
+        _check(lib().pgo_comm_create_rccl(buf, rank, world, device, C.byref(h)))
+        return cls(h, rank, world)
+
+    @classmethod
+    def shm(cls, name: str, rank: int, world: int, device: int = 0) -> "Comm":
+        h = C.c_void_p()
+        _check(lib().pgo_comm_create_shm(name.encode(), rank, world, device, C.byref(h)))
+        return cls(h, rank, world)
+
+    def close(self):
+        if self._h:
+            lib().pgo_comm_destroy(self._h)
+            self._h = None
+
+
+class Solver:
+    """Problem assembly + ceres::Solve replacement (reference main.cpp:66-163)."""
+
+    def __init__(self, graph: Graph, options: Options | None = None, comm: Comm | None = None, device: int = 0):
+        self.graph = graph
+        self.options = options if options is not None else Options()
+        self.comm = comm
+        self._h = C.c_void_p()
+        _check(lib().pgo_create_from_graph(C.byref(self._h), graph._h, C.byref(self.options),
+                                           comm._h if comm else None, device))
+        self.n_poses, self.n_edges = graph.n_poses, graph.n_edges
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pgo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def evaluate(self, poses=None, apply_loss=True, want_r=True, want_J=True):
+        p = np.ascontiguousarray(poses, np.float64) if poses is not None else None
+        r = np.zeros((self.n_edges, 3)) if want_r else None
+        J = np.zeros((self.n_edges, 18)) if want_J else None
+        cost = C.c_double()
+        _check(lib().pgo_eval(self._h, _dp(p), int(apply_loss), C.byref(cost), _dp(r), _dp(J)))
+        return cost.value, r, J
+
+    def solve(self) -> Summary:
+        s = Summary()
+        _check(lib().pgo_solve(self._h, C.byref(s)))
+        return s
+
+    def lm_begin(self):
+        _check(lib().pgo_lm_begin(self._h))
+
+    def lm_step(self, n_iters: int = 1):
+        s, done = Summary(), C.c_int32()
+        _check(lib().pgo_lm_step(self._h, n_iters, C.byref(done), C.byref(s)))
+        return bool(done.value), s
+
+    def iter_records(self):
+        n = lib().pgo_num_iter_records(self._h)
+        arr = (IterRecord * max(n, 1))()
+        _check(lib().pgo_get_iter_records(self._h, arr, n))
+        return [arr[i].as_dict() for i in range(n)]
+
+    def poses(self):
+        out = np.zeros((self.n_poses, 3))
+        _check(lib().pgo_get_poses(self._h, _dp(out)))
+        return out
+
+    def set_poses(self, poses):
+        p = np.ascontiguousarray(poses, np.float64)
+        _check(lib().pgo_set_poses(self._h, _dp(p)))
+
+    def write_back(self):
+        """poses are optimised IN PLACE in Node::p in the reference (main.cpp:99,163)"""
+        self.graph.poses[:] = self.poses()
+
+    # ---- kernel-level entry points
+    def normal_eq(self):
+        g, hd = np.zeros(3 * self.n_poses), np.zeros((self.n_poses, 9))
+        _check(lib().pgo_debug_normal_eq(self._h, _dp(g), _dp(hd)))
+        return g, hd
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.zeros_like(x)
+        _check(lib().pgo_debug_spmv(self._h, _dp(x), _dp(y)))
+        return y
+
+    def bench_eval(self, reps=10, with_jacobian=True) -> KernelStats:
+        k = KernelStats()
+        _check(lib().pgo_bench_eval(self._h, reps, int(with_jacobian), C.byref(k)))
+        return k
+
+    def bench_assemble(self, reps=10) -> KernelStats:
+        k = KernelStats()
+        _check(lib().pgo_bench_assemble(self._h, reps, C.byref(k)))
+        return k
+
+    def bench_spmv(self, reps=10) -> KernelStats:
+        k = KernelStats()
+        _check(lib().pgo_bench_spmv(self._h, reps, C.byref(k)))
+        return k

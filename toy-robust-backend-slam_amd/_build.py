@@ -1,0 +1,59 @@
+"""In-tree build of libpgo.so (hipcc, gfx950 only).  No JIT cache: the .so lives next to this
+file so that it travels with the repository snapshot to the GPU box."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libpgo.so")
+SOURCES = ["host_graph.cpp", "structure.cpp", "comm.cpp", "solver.hip"]
+HEADERS = ["pgo_internal.h", "comm.h", "kernels.hip.h", os.path.join(ROOT, "include", "pgo.h")]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libpgo.so cannot be built (there is no CPU fallback)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB + ".tmp", "-lrccl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+def build_cli(force: bool = False) -> str:
+    """The C++ host mirror of the reference's `main` (DATASET NUM_OUTLIER_LOOPS METHOD)."""
+    out = os.path.join(HERE, "host", "main")
+    src = os.path.join(HERE, "host", "main.cpp")
+    if not os.path.exists(src):
+        return ""
+    hdrs = [os.path.join(HERE, "host", h) for h in os.listdir(os.path.join(HERE, "host")) if h.endswith(".h")]
+    if (not force and os.path.exists(out) and
+            all(os.path.getmtime(out) >= os.path.getmtime(p) for p in [src, LIB] + hdrs)):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "host"), src,
+           "-o", out, "-L" + HERE, "-lpgo", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+    subprocess.check_call(cmd)
+    return out

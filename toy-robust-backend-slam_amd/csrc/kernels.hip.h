@@ -1,0 +1,650 @@
+// HIP kernels of the pose-graph backend, written for gfx950 (CDNA4, wave64).
+// Everything here is HBM-bandwidth bound fp64 work on 3x3 blocks: no MFMA.
+//
+//   K1  k_edge_eval      fused per-edge SE(2) residual + 3x6 Jacobian + DCS weight + Huber
+//                        corrector + Jacobi column scaling  (reference: src/ceres_error.cpp:42-94,
+//                        135-196 evaluated through AutoDiffCostFunction, main.cpp:66-68 loss)
+//   K2  k_assemble       row-tiled segmented reduction of (JS)'(JS) and S J'r into
+//                        diagonal planes + one off-diagonal 3x3 block per incidence (block CSR)
+//   K3  k_spmv           y = ((JS)'(JS) + D'D) p on that block CSR, fused p.y partial
+//   K4  k_prepare        LM diagonal + block-Jacobi (3x3 inverse) preconditioner
+//   K5  k_cg_*           fused PCG vector updates with in-kernel dot partials
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pgo {
+namespace dev {
+
+constexpr int WG = 256;          // workgroup size of every kernel here (4 waves)
+constexpr int REC = 22;          // doubles per edge record: J (18, row-major 3x6) | r (3) | cost (1)
+constexpr int REC_LDS = 23;      // odd stride => conflict-free ds_write_b64 when staging records
+
+// ------------------------------------------------------------- reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // lane 0
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+// sum over the workgroup, result broadcast to every thread.  sh: >= 5 doubles.
+__device__ __forceinline__ double block_sum_bcast(double v, double* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();  // sh may still be read from a previous call
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sh[4] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return sh[4];
+}
+__device__ __forceinline__ double block_max_bcast(double v, double* sh) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sh[4] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+  __syncthreads();
+  return sh[4];
+}
+// every workgroup sums the same `n` partials in the same order => identical value
+// everywhere, no atomics, bitwise reproducible.
+__device__ __forceinline__ double sum_partials_bcast(const double* __restrict__ part, int n, double* sh) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += WG) v += part[i];
+  return block_sum_bcast(v, sh);
+}
+
+// ------------------------------------------------------------------- K1
+struct EdgeArgs {
+  const double* poses;    // [.. x 3] global pose positions
+  const double* scale;    // [.. x 3] Jacobi column scales (0 on the constant pose) or nullptr = 1
+  const int32_t* ia;
+  const int32_t* ib;
+  const double* mx;
+  const double* my;
+  const double* mt;
+  const uint8_t* flags;   // bit0 DCS, bit1 cost counted on this rank
+  int32_t n_edges;
+  int32_t apply_loss;
+  double phi;
+  double huber_delta;
+};
+
+// One lane per edge.  Algorithmic bytes per edge: 8 (ia,ib) + 24 (meas) + 1 (flags) +
+// 48 (two poses) [+ 48 scales] read, 176 written with the Jacobian, 0 without.
+template <bool WITH_JAC>
+__global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict__ jr,
+                                                  double* __restrict__ cost_part, int* __restrict__ bad) {
+  __shared__ double stage[WITH_JAC ? WG * REC_LDS : 1];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  const int64_t e0 = (int64_t)blockIdx.x * WG;
+  const int64_t e = e0 + tid;
+  double cost = 0.0;
+  if (e < A.n_edges) {
+    const int a = A.ia[e], b = A.ib[e];
+    const double dx = A.mx[e], dy = A.my[e], dth = A.mt[e];
+    const unsigned fl = A.flags[e];
+    const double x1 = A.poses[3 * (int64_t)a], y1 = A.poses[3 * (int64_t)a + 1], t1 = A.poses[3 * (int64_t)a + 2];
+    const double x2 = A.poses[3 * (int64_t)b], y2 = A.poses[3 * (int64_t)b + 1], t2 = A.poses[3 * (int64_t)b + 2];
+    double s1, c1, s2, c2, sd, cd;
+    sincos(t1, &s1, &c1);
+    sincos(t2, &s2, &c2);
+    sincos(dth, &sd, &cd);
+    // diff = T^-1 (Ta^-1 Tb)  in closed form
+    const double Dx = x2 - x1, Dy = y2 - y1;
+    const double pa = c1 * Dx + s1 * Dy, pb = -s1 * Dx + c1 * Dy;  // R(t1)' D
+    const double ux = pa - dx, uy = pb - dy;
+    double ex = cd * ux + sd * uy, ey = -sd * ux + cd * uy;         // R(dth)' u
+    const double c21 = c1 * c2 + s1 * s2, s21 = c1 * s2 - s1 * c2;  // R(t2 - t1)
+    const double sind = cd * s21 - sd * c21, cosd = cd * c21 + sd * s21;
+    double et = asin(sind);
+    double J[18];
+    if (WITH_JAC) {
+      const double cm = c1 * cd - s1 * sd, sm = s1 * cd + c1 * sd;  // R(t1 + dth)
+      const double g = cosd / sqrt(1.0 - sind * sind);              // d asin(u) = du / sqrt(1-u^2)
+      J[0] = -cm;  J[1] = -sm;  J[2] = cd * pb - sd * pa;   J[3] = cm;   J[4] = sm;   J[5] = 0.0;
+      J[6] = sm;   J[7] = -cm;  J[8] = -sd * pb - cd * pa;  J[9] = -sm;  J[10] = cm;  J[11] = 0.0;
+      J[12] = 0.0; J[13] = 0.0; J[14] = -g;                 J[15] = 0.0; J[16] = 0.0; J[17] = g;
+    }
+    if (fl & 1u) {  // DCS (src/ceres_error.cpp:185-193): psi = min(1, sqrt(2 phi / (phi + ex^2 + ey^2)))
+      const double res = ex * ex + ey * ey;
+      const double psi_org = sqrt(2.0 * A.phi / (A.phi + res));
+      if (psi_org < 1.0) {
+        if (WITH_JAC) {
+          const double k = -psi_org / (A.phi + res);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const double dpsi = k * (ex * J[c] + ey * J[6 + c]);
+            J[c] = psi_org * J[c] + ex * dpsi;
+            J[6 + c] = psi_org * J[6 + c] + ey * dpsi;
+            J[12 + c] = psi_org * J[12 + c] + et * dpsi;
+          }
+        }
+        ex *= psi_org;
+        ey *= psi_org;
+        et *= psi_org;
+      }
+    }
+    const double s = ex * ex + ey * ey + et * et;
+    double rho0 = s, sc = 1.0;
+    if (A.huber_delta > 0.0) {  // ceres::HuberLoss(a): b = a^2
+      const double bq = A.huber_delta * A.huber_delta;
+      if (s > bq) {
+        const double rs = sqrt(s);
+        rho0 = 2.0 * A.huber_delta * rs - bq;
+        double rho1 = A.huber_delta / rs;
+        rho1 = fmax(rho1, 2.2250738585072014e-308);
+        if (A.apply_loss) sc = sqrt(rho1);
+      }
+    }
+    const double ecost = 0.5 * rho0;
+    if (fl & 2u) cost = ecost;
+    bool finite = isfinite(s);
+    if (WITH_JAC) {
+      double sa0 = 1.0, sa1 = 1.0, sa2 = 1.0, sb0 = 1.0, sb1 = 1.0, sb2 = 1.0;
+      if (A.scale) {
+        sa0 = A.scale[3 * (int64_t)a]; sa1 = A.scale[3 * (int64_t)a + 1]; sa2 = A.scale[3 * (int64_t)a + 2];
+        sb0 = A.scale[3 * (int64_t)b]; sb1 = A.scale[3 * (int64_t)b + 1]; sb2 = A.scale[3 * (int64_t)b + 2];
+      }
+      double* st = stage + tid * REC_LDS;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double v0 = sc * J[6 * i + 0], v1 = sc * J[6 * i + 1], v2 = sc * J[6 * i + 2];
+        const double v3 = sc * J[6 * i + 3], v4 = sc * J[6 * i + 4], v5 = sc * J[6 * i + 5];
+        finite = finite && isfinite(v0) && isfinite(v1) && isfinite(v2) && isfinite(v3) && isfinite(v4) && isfinite(v5);
+        st[6 * i + 0] = v0 * sa0; st[6 * i + 1] = v1 * sa1; st[6 * i + 2] = v2 * sa2;
+        st[6 * i + 3] = v3 * sb0; st[6 * i + 4] = v4 * sb1; st[6 * i + 5] = v5 * sb2;
+      }
+      st[18] = sc * ex;
+      st[19] = sc * ey;
+      st[20] = sc * et;
+      st[21] = ecost;
+    }
+    if (!finite) atomicOr(bad, 1);
+  }
+  if (WITH_JAC) {
+    // transpose through LDS so that the 176-byte records leave as 16-byte-per-lane
+    // coalesced stores (a lane-per-record store would touch ~90 lines per instruction)
+    __syncthreads();
+    int64_t nvalid = A.n_edges - e0;
+    if (nvalid > WG) nvalid = WG;
+    const int ndbl = (int)nvalid * REC;
+    double* out = jr + e0 * REC;  // 16-byte aligned: e0 * 176
+    for (int j = tid * 2; j < ndbl; j += 2 * WG) {
+      const int le = j / REC, c = j - le * REC;  // REC is even => (j, j+1) stay in one record
+      double2 v;
+      v.x = stage[le * REC_LDS + c];
+      v.y = stage[le * REC_LDS + c + 1];
+      *reinterpret_cast<double2*>(out + j) = v;
+    }
+  }
+  const double tot = block_sum_bcast(cost, red);
+  if (tid == 0) cost_part[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------- K2
+struct AsmArgs {
+  const double* jr;          // edge records
+  const int32_t* inc_ptr;    // n_loc + 1
+  const int32_t* inc_edge;   // (local edge << 1) | side
+  const int32_t* tile_row;   // n_tiles + 1 (local rows)
+  int32_t n_tiles;
+  int32_t n_loc;
+  int64_t inc_stride;        // plane stride of hoff (>= n_inc)
+  double* hoff;              // 9 planes [inc_stride]: (J_self)'(J_other), row-major 3x3
+  double* hd;                // 6 planes [n_loc]: d00 d01 d02 d11 d12 d22 of (J_self)'(J_self) summed
+  double* gs;                // [n_loc x 3]: sum (J_self)' r
+};
+
+// One workgroup per tile of rows.  Phase A: one lane per incidence reads the
+// 176-byte edge record (11 x 16-byte loads), forms the off-diagonal block (stored
+// straight to its plane slot, coalesced) and its diagonal/gradient contribution
+// (9 doubles, staged in LDS).  Phase B: one thread per (row, component) sums its
+// row's staged contributions in incidence order -- a fixed order, so the result is
+// bitwise reproducible and independent of the sharding.
+__global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
+  __shared__ double scr[9][WG];
+  const int tid = threadIdx.x;
+  for (int t = blockIdx.x; t < A.n_tiles; t += gridDim.x) {
+    const int r0 = A.tile_row[t], r1 = A.tile_row[t + 1];
+    const int nrows = r1 - r0;
+    const int q0 = A.inc_ptr[r0], q1 = A.inc_ptr[r1];
+    double acc = 0.0;  // used only by the single-row multi-chunk case (tid < 9)
+    const bool multi = (q1 - q0) > WG;
+    for (int base = q0; base < q1 || base == q0; base += WG) {
+      const int q = base + tid;
+      if (q < q1) {
+        const int ed = A.inc_edge[q];
+        const double2* rp = reinterpret_cast<const double2*>(A.jr + (int64_t)(ed >> 1) * REC);
+        double R[REC];
+#pragma unroll
+        for (int k = 0; k < REC / 2; ++k) {
+          const double2 v = rp[k];
+          R[2 * k] = v.x;
+          R[2 * k + 1] = v.y;
+        }
+        const int cs = (ed & 1) ? 3 : 0, co = 3 - cs;
+        double S[9], O[9];  // S[k*3+a] = J[k][cs+a]
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            S[3 * k + a] = (ed & 1) ? R[6 * k + 3 + a] : R[6 * k + a];
+            O[3 * k + a] = (ed & 1) ? R[6 * k + a] : R[6 * k + 3 + a];
+          }
+        (void)cs; (void)co;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+            A.hoff[(int64_t)(3 * a + b) * A.inc_stride + q] = S[a] * O[b] + S[3 + a] * O[3 + b] + S[6 + a] * O[6 + b];
+        scr[0][tid] = S[0] * S[0] + S[3] * S[3] + S[6] * S[6];
+        scr[1][tid] = S[0] * S[1] + S[3] * S[4] + S[6] * S[7];
+        scr[2][tid] = S[0] * S[2] + S[3] * S[5] + S[6] * S[8];
+        scr[3][tid] = S[1] * S[1] + S[4] * S[4] + S[7] * S[7];
+        scr[4][tid] = S[1] * S[2] + S[4] * S[5] + S[7] * S[8];
+        scr[5][tid] = S[2] * S[2] + S[5] * S[5] + S[8] * S[8];
+        scr[6][tid] = S[0] * R[18] + S[3] * R[19] + S[6] * R[20];
+        scr[7][tid] = S[1] * R[18] + S[4] * R[19] + S[7] * R[20];
+        scr[8][tid] = S[2] * R[18] + S[5] * R[19] + S[8] * R[20];
+      }
+      __syncthreads();
+      for (int idx = tid; idx < nrows * 9; idx += WG) {
+        const int c = idx / nrows, rl = idx - c * nrows;
+        const int row = r0 + rl;
+        int lo = A.inc_ptr[row], hi = A.inc_ptr[row + 1];
+        lo = max(lo, base) - base;
+        hi = min(hi, base + WG) - base;
+        double s = 0.0;
+        for (int j = lo; j < hi; ++j) s += scr[c][j];
+        if (multi) {
+          acc += s;  // nrows == 1: idx == tid == c
+        } else if (c < 6) {
+          A.hd[(int64_t)c * A.n_loc + row] = s;
+        } else {
+          A.gs[3 * (int64_t)row + (c - 6)] = s;
+        }
+      }
+      __syncthreads();
+      if (q1 == q0) break;
+    }
+    if (multi && tid < 9) {
+      if (tid < 6) A.hd[(int64_t)tid * A.n_loc + r0] = acc;
+      else A.gs[3 * (int64_t)r0 + (tid - 6)] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------- K3
+struct SpmvArgs {
+  const int32_t* inc_ptr;
+  const int32_t* inc_col;    // global pose position of the column block
+  const int32_t* tile_row;
+  int32_t n_tiles;
+  int32_t n_loc;
+  int32_t lo;                // first owned global row
+  int32_t with_d2;
+  int64_t inc_stride;
+  const double* hoff;        // 9 planes
+  const double* hd;          // 6 planes
+  const double* d2;          // [n_loc x 3] LM diagonal D'D
+  const double* p;           // gathered vector, GLOBAL indexing [.. x 3]
+  double* y;                 // [n_loc x 3]
+  double* dot_part;          // [gridDim.x] partial of p_owned . y
+  const int32_t* done;       // skip when *done != 0 (nullptr: never)
+};
+
+// Algorithmic bytes: 76 per off-diagonal block (72 value + 4 column index) + per row
+// 48 (diagonal planes) + 24 (D'D) + 4 (row pointer) + 24 (y) + 24 (p, counted once).
+__global__ __launch_bounds__(WG) void k_spmv(SpmvArgs A) {
+  __shared__ double scr[3][WG];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  if (A.done && *A.done) return;
+  double dot = 0.0;
+  for (int t = blockIdx.x; t < A.n_tiles; t += gridDim.x) {
+    const int r0 = A.tile_row[t], r1 = A.tile_row[t + 1];
+    const int nrows = r1 - r0;
+    const int q0 = A.inc_ptr[r0], q1 = A.inc_ptr[r1];
+    const bool multi = (q1 - q0) > WG;
+    double acc = 0.0;
+    for (int base = q0; base < q1 || base == q0; base += WG) {
+      const int q = base + tid;
+      if (q < q1) {
+        const int64_t col = A.inc_col[q];
+        const double p0 = A.p[3 * col], p1 = A.p[3 * col + 1], p2 = A.p[3 * col + 2];
+        const double* h = A.hoff + q;
+        const int64_t S = A.inc_stride;
+        scr[0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
+        scr[1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
+        scr[2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < nrows * 3; idx += WG) {
+        const int a = idx / nrows, rl = idx - a * nrows;
+        const int row = r0 + rl;
+        int lo = A.inc_ptr[row], hi = A.inc_ptr[row + 1];
+        lo = max(lo, base) - base;
+        hi = min(hi, base + WG) - base;
+        double s = 0.0;
+        for (int j = lo; j < hi; ++j) s += scr[a][j];
+        if (multi) {
+          acc += s;
+        } else {
+          // diagonal block row a of the symmetric 3x3 + LM diagonal
+          const double* pr = A.p + 3 * (int64_t)(A.lo + row);
+          const int64_t n = A.n_loc;
+          const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
+          double d = A.hd[(int64_t)a * n + row] * pr[0];
+          d += A.hd[(int64_t)i1 * n + row] * pr[1];
+          d += A.hd[(int64_t)i2 * n + row] * pr[2];
+          if (A.with_d2) d += A.d2[3 * (int64_t)row + a] * pr[a];
+          s += d;
+          A.y[3 * (int64_t)row + a] = s;
+          dot += pr[a] * s;
+        }
+      }
+      __syncthreads();
+      if (q1 == q0) break;
+    }
+    if (multi && tid < 3) {  // single heavy row
+      const int a = tid, row = r0;
+      const double* pr = A.p + 3 * (int64_t)(A.lo + row);
+      const int64_t n = A.n_loc;
+      const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
+      double d = A.hd[(int64_t)a * n + row] * pr[0];
+      d += A.hd[(int64_t)i1 * n + row] * pr[1];
+      d += A.hd[(int64_t)i2 * n + row] * pr[2];
+      if (A.with_d2) d += A.d2[3 * (int64_t)row + a] * pr[a];
+      const double s = acc + d;
+      A.y[3 * (int64_t)row + a] = s;
+      dot += pr[a] * s;
+    }
+  }
+  const double tot = block_sum_bcast(dot, red);
+  if (tid == 0) A.dot_part[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------ per-row kernels
+// symmetric plane indices: 0:d00 1:d01 2:d02 3:d11 4:d12 5:d22
+
+// Jacobi column scaling 1/(1 + ||J col||) from the unscaled diagonal (Ceres
+// TrustRegionMinimizer, iteration 0); 0 on the constant pose.
+__global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo, int fixed, int enabled,
+                               double* __restrict__ scale) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_loc) return;
+  const int64_t n = n_loc;
+  double s0 = 1.0, s1 = 1.0, s2 = 1.0;
+  if (enabled) {
+    s0 = 1.0 / (1.0 + sqrt(hd[row]));
+    s1 = 1.0 / (1.0 + sqrt(hd[3 * n + row]));
+    s2 = 1.0 / (1.0 + sqrt(hd[5 * n + row]));
+  }
+  if (lo + row == fixed) s0 = s1 = s2 = 0.0;
+  double* o = scale + 3 * (int64_t)(lo + row);
+  o[0] = s0;
+  o[1] = s1;
+  o[2] = s2;
+}
+
+// LM diagonal D'D = clamp(diag(H), min, max) / radius and the block-Jacobi
+// preconditioner M^-1 = (H_ii + D'D)^-1  (symmetric 3x3, 6 planes).
+__global__ void k_prepare(const double* __restrict__ hd, int n_loc, int lo, int fixed, double radius, double dmin,
+                          double dmax, double* __restrict__ d2, double* __restrict__ minv) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_loc) return;
+  const int64_t n = n_loc;
+  double a00 = hd[row], a01 = hd[n + row], a02 = hd[2 * n + row], a11 = hd[3 * n + row], a12 = hd[4 * n + row],
+         a22 = hd[5 * n + row];
+  double e0 = fmin(fmax(a00, dmin), dmax) / radius;
+  double e1 = fmin(fmax(a11, dmin), dmax) / radius;
+  double e2 = fmin(fmax(a22, dmin), dmax) / radius;
+  if (lo + row == fixed) e0 = e1 = e2 = 1.0;  // decoupled identity row: the constant pose never moves
+  d2[3 * (int64_t)row] = e0;
+  d2[3 * (int64_t)row + 1] = e1;
+  d2[3 * (int64_t)row + 2] = e2;
+  a00 += e0;
+  a11 += e1;
+  a22 += e2;
+  const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02;
+  const double id = 1.0 / det;
+  minv[row] = c00 * id;
+  minv[n + row] = c01 * id;
+  minv[2 * n + row] = c02 * id;
+  minv[3 * n + row] = (a00 * a22 - a02 * a02) * id;
+  minv[4 * n + row] = (a01 * a02 - a00 * a12) * id;
+  minv[5 * n + row] = (a00 * a11 - a01 * a01) * id;
+}
+
+// max_i |g_i| of the UNSCALED gradient g = gs / s over the free parameters (Ceres
+// gradient_max_norm); partial max per workgroup.
+__global__ __launch_bounds__(WG) void k_grad_max(const double* __restrict__ gs, const double* __restrict__ scale,
+                                                 int n_loc, int lo, double* __restrict__ part) {
+  __shared__ double red[8];
+  double m = 0.0;
+  const int64_t n3 = 3 * (int64_t)n_loc;
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n3; i += (int64_t)gridDim.x * WG) {
+    const double s = scale[3 * (int64_t)lo + i];
+    if (s > 0.0) m = fmax(m, fabs(gs[i] / s));
+  }
+  m = block_max_bcast(m, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+
+// out[k] = reduce(part_k[0..n_k)) for up to 4 partial arrays; one workgroup.
+struct FinArgs {
+  const double* part[4];
+  int32_t n[4];
+  int32_t is_max[4];
+  int32_t count;
+  double* out;
+};
+__global__ __launch_bounds__(WG) void k_finalize(FinArgs A) {
+  __shared__ double red[8];
+  for (int k = 0; k < A.count; ++k) {
+    double v = 0.0;
+    if (A.is_max[k]) {
+      for (int i = threadIdx.x; i < A.n[k]; i += WG) v = fmax(v, A.part[k][i]);
+      v = block_max_bcast(v, red);
+    } else {
+      v = sum_partials_bcast(A.part[k], A.n[k], red);
+    }
+    if (threadIdx.x == 0) A.out[k] = v;
+  }
+}
+
+// ------------------------------------------------------------------- K5
+struct CgState {       // lives in device memory
+  double rz[2];        // r.z, double-buffered by iteration parity
+  double bb;           // b.b
+  double rr;           // r.r after the latest update
+  double tol2;         // (rtol^2) b.b
+  int32_t done;
+  int32_t iters;
+};
+
+struct CgVec {
+  int32_t n_loc;
+  int32_t lo;
+  const double* minv;  // 6 planes
+  double* y;           // solution   [n_loc x 3]
+  double* r;           // residual
+  double* z;           // M^-1 r
+  double* ap;          // A p
+  double* p;           // search direction, GLOBAL indexing (gathered by K3)
+  CgState* st;
+};
+
+__device__ __forceinline__ void minv_apply(const double* __restrict__ minv, int64_t n, int row, double r0, double r1,
+                                           double r2, double& z0, double& z1, double& z2) {
+  const double m00 = minv[row], m01 = minv[n + row], m02 = minv[2 * n + row], m11 = minv[3 * n + row],
+               m12 = minv[4 * n + row], m22 = minv[5 * n + row];
+  z0 = m00 * r0 + m01 * r1 + m02 * r2;
+  z1 = m01 * r0 + m11 * r1 + m12 * r2;
+  z2 = m02 * r0 + m12 * r1 + m22 * r2;
+}
+
+// y = 0, r = b, z = M^-1 r, p = z; partials of r.z and b.b
+__global__ __launch_bounds__(WG) void k_cg_init(CgVec V, const double* __restrict__ b, double* __restrict__ part_rz,
+                                                double* __restrict__ part_bb) {
+  __shared__ double red[8];
+  double rz = 0.0, bb = 0.0;
+  const int64_t n = V.n_loc;
+  for (int row = blockIdx.x * WG + threadIdx.x; row < V.n_loc; row += gridDim.x * WG) {
+    const double r0 = b[3 * (int64_t)row], r1 = b[3 * (int64_t)row + 1], r2 = b[3 * (int64_t)row + 2];
+    double z0, z1, z2;
+    minv_apply(V.minv, n, row, r0, r1, r2, z0, z1, z2);
+    double* o;
+    o = V.y + 3 * (int64_t)row; o[0] = 0.0; o[1] = 0.0; o[2] = 0.0;
+    o = V.r + 3 * (int64_t)row; o[0] = r0; o[1] = r1; o[2] = r2;
+    o = V.z + 3 * (int64_t)row; o[0] = z0; o[1] = z1; o[2] = z2;
+    o = V.p + 3 * (int64_t)(V.lo + row); o[0] = z0; o[1] = z1; o[2] = z2;
+    rz += r0 * z0 + r1 * z1 + r2 * z2;
+    bb += r0 * r0 + r1 * r1 + r2 * r2;
+  }
+  rz = block_sum_bcast(rz, red);
+  bb = block_sum_bcast(bb, red);
+  if (threadIdx.x == 0) {
+    part_rz[blockIdx.x] = rz;
+    part_bb[blockIdx.x] = bb;
+  }
+}
+
+// scal[0] = r.z, scal[1] = b.b (already reduced over workgroups and ranks)
+__global__ void k_cg_init_fin(CgState* st, const double* __restrict__ scal, double rtol) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    st->rz[0] = scal[0];
+    st->rz[1] = 0.0;
+    st->bb = scal[1];
+    st->rr = scal[1];
+    st->tol2 = rtol * rtol * scal[1];
+    st->done = (scal[1] == 0.0) ? 1 : 0;
+    st->iters = 0;
+  }
+}
+
+// alpha = rz / p.Ap ; y += alpha p ; r -= alpha Ap ; z = M^-1 r ; partials r.z, r.r
+__global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, const double* __restrict__ part_pap, int n_pap,
+                                                   double* __restrict__ part_rz, double* __restrict__ part_rr) {
+  __shared__ double red[8];
+  if (V.st->done) return;
+  const double pap = sum_partials_bcast(part_pap, n_pap, red);
+  const double alpha = V.st->rz[parity] / pap;
+  double rz = 0.0, rr = 0.0;
+  const int64_t n = V.n_loc;
+  for (int row = blockIdx.x * WG + threadIdx.x; row < V.n_loc; row += gridDim.x * WG) {
+    const double* pp = V.p + 3 * (int64_t)(V.lo + row);
+    double* yy = V.y + 3 * (int64_t)row;
+    double* rp = V.r + 3 * (int64_t)row;
+    const double* ap = V.ap + 3 * (int64_t)row;
+    yy[0] += alpha * pp[0];
+    yy[1] += alpha * pp[1];
+    yy[2] += alpha * pp[2];
+    const double r0 = rp[0] - alpha * ap[0], r1 = rp[1] - alpha * ap[1], r2 = rp[2] - alpha * ap[2];
+    rp[0] = r0;
+    rp[1] = r1;
+    rp[2] = r2;
+    double z0, z1, z2;
+    minv_apply(V.minv, n, row, r0, r1, r2, z0, z1, z2);
+    double* zz = V.z + 3 * (int64_t)row;
+    zz[0] = z0;
+    zz[1] = z1;
+    zz[2] = z2;
+    rz += r0 * z0 + r1 * z1 + r2 * z2;
+    rr += r0 * r0 + r1 * r1 + r2 * r2;
+  }
+  rz = block_sum_bcast(rz, red);
+  rr = block_sum_bcast(rr, red);
+  if (threadIdx.x == 0) {
+    part_rz[blockIdx.x] = rz;
+    part_rr[blockIdx.x] = rr;
+  }
+}
+
+// beta = rz_new / rz ; p = z + beta p ; workgroup 0 publishes the new scalars
+__global__ __launch_bounds__(WG) void k_cg_update2(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
+                                                   const double* __restrict__ part_rr, int n_rr) {
+  __shared__ double red[8];
+  if (V.st->done) return;
+  const double rz_new = sum_partials_bcast(part_rz, n_rz, red);
+  const double rr = sum_partials_bcast(part_rr, n_rr, red);
+  const double rz_old = V.st->rz[parity];
+  const double tol2 = V.st->tol2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    V.st->rz[parity ^ 1] = rz_new;
+    V.st->rr = rr;
+    V.st->iters += 1;
+  }
+  if (rr <= tol2) {  // converged: leave p alone, freeze the solve (same decision in every workgroup)
+    if (blockIdx.x == 0 && threadIdx.x == 0) V.st->done = 1;
+    return;
+  }
+  const double beta = rz_new / rz_old;
+  const int64_t n3 = 3 * (int64_t)V.n_loc;
+  double* p = V.p + 3 * (int64_t)V.lo;
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n3; i += (int64_t)gridDim.x * WG)
+    p[i] = V.z[i] + beta * p[i];
+}
+
+// partials of a.b over n doubles
+__global__ __launch_bounds__(WG) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                            double* __restrict__ part) {
+  __shared__ double red[8];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) s += a[i] * b[i];
+  s = block_sum_bcast(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void k_flag_to_double(const int* __restrict__ flag, double* __restrict__ out) { out[0] = (double)(*flag); }
+
+// copy the owned part of a local vector into a globally indexed one
+__global__ void k_scatter_owned(int n_loc, int lo, const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t n3 = 3 * (int64_t)n_loc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x)
+    dst[3 * (int64_t)lo + i] = src[i];
+}
+
+// candidate = x - S y on the owned rows; partials of |step|^2
+__global__ __launch_bounds__(WG) void k_candidate(int n_loc, int lo, const double* __restrict__ x,
+                                                  const double* __restrict__ scale, const double* __restrict__ y,
+                                                  double* __restrict__ cand, double* __restrict__ part_step2) {
+  __shared__ double red[8];
+  double s2 = 0.0;
+  const int64_t n3 = 3 * (int64_t)n_loc, off = 3 * (int64_t)lo;
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n3; i += (int64_t)gridDim.x * WG) {
+    const double d = -scale[off + i] * y[i];
+    cand[off + i] = x[off + i] + d;
+    s2 += d * d;
+  }
+  s2 = block_sum_bcast(s2, red);
+  if (threadIdx.x == 0) part_step2[blockIdx.x] = s2;
+}
+
+// partials of |x|^2 over the owned free parameters (scale == 0 marks the constant pose)
+__global__ __launch_bounds__(WG) void k_xnorm(int n_loc, int lo, const double* __restrict__ x,
+                                              const double* __restrict__ scale, double* __restrict__ part) {
+  __shared__ double red[8];
+  double s2 = 0.0;
+  const int64_t n3 = 3 * (int64_t)n_loc, off = 3 * (int64_t)lo;
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n3; i += (int64_t)gridDim.x * WG)
+    if (scale[off + i] > 0.0) s2 += x[off + i] * x[off + i];
+  s2 = block_sum_bcast(s2, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s2;
+}
+
+__global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace dev
+}  // namespace pgo

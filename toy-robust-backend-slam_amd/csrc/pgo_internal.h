@@ -1,0 +1,77 @@
+// Internal declarations shared by the translation units of libpgo.so.
+// Nothing here is part of the C-ABI (include/pgo.h is).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pgo.h"
+
+namespace pgo {
+
+// thread-local detail text behind pgo_last_error()
+void set_error(const std::string& msg);
+int fail(int status, const std::string& msg);
+
+// ---------------------------------------------------------------- host graph
+// Flat-array replacement of ReadG2O's nNodes / nEdgesOdometry / nEdgesClosure /
+// nEdgesBogus (reference include/g2o_util.h:174-177).  Edges are kept in
+// residual-block order: odometry, closure, bogus (reference main.cpp:95-150).
+struct Graph {
+  std::vector<int32_t> pose_id;   // Node::index as read from the file
+  std::vector<double> pose;       // N x 3
+  std::vector<int32_t> ea, eb;    // positions into pose[] (not ids), as the reference indexes nNodes[]
+  std::vector<double> meas;       // E x 3
+  std::vector<double> info;       // E x 6 (parsed, never used by METHOD 0/1)
+  std::vector<uint8_t> kind;      // 0 odometry, 1 closure, 2 bogus
+  int32_t n_kind[3] = {0, 0, 0};
+
+  int32_t n_poses() const { return (int32_t)pose_id.size(); }
+  int32_t n_edges() const { return (int32_t)ea.size(); }
+  // append keeping the odometry|closure|bogus grouping
+  void insert_edge(int32_t a, int32_t b, const double m[3], const double inf[6], int kind);
+};
+
+// -------------------------------------------------------- shard structure
+// Everything the device needs to know about the rows [lo, hi) of J'J owned by
+// one rank.  Built once per graph on the host (structure.cpp).
+struct ShardStructure {
+  int32_t n_poses = 0;       // N (global)
+  int32_t world = 1, rank = 0;
+  int32_t rows_per_rank = 0; // ceil(N / world); rank r owns [r*rpr, min(N,(r+1)*rpr))
+  int32_t lo = 0, hi = 0;    // owned rows
+  int32_t n_loc = 0;         // hi - lo
+
+  // local edges = every edge with at least one endpoint in [lo,hi), sorted by
+  // (min endpoint, max endpoint, original index)
+  int32_t n_edges_local = 0;
+  int32_t n_cut = 0;                    // local edges with one endpoint outside [lo,hi)
+  std::vector<int32_t> orig_edge;       // local -> caller's edge index
+  std::vector<int32_t> ia, ib;          // global pose positions
+  std::vector<double> mx, my, mt;       // measurement planes
+  std::vector<uint8_t> flags;           // bit0: DCS applies, bit1: cost counted on this rank
+
+  // incidences of the owned rows (row-major):  row i -> [inc_ptr[i-lo], inc_ptr[i-lo+1])
+  // each incidence = (local edge, side) ; side 0: row is Edge::a, 1: row is Edge::b
+  int64_t n_inc = 0;
+  std::vector<int32_t> inc_ptr;         // n_loc + 1
+  std::vector<int32_t> inc_edge;        // (local edge << 1) | side
+  std::vector<int32_t> inc_col;         // global pose position of the other endpoint
+
+  // tiles: contiguous row ranges with <= TILE_INC incidences (a row with more
+  // incidences forms a tile of its own and is processed in chunks)
+  std::vector<int32_t> tile_row;        // n_tiles + 1, LOCAL row index
+  int32_t n_tiles() const { return (int32_t)tile_row.size() - 1; }
+};
+
+constexpr int TILE_INC = 256;
+
+int build_shard_structure(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
+                          const double* meas, const uint8_t* kind, int method, int world, int rank,
+                          ShardStructure* out);
+
+}  // namespace pgo
+
+struct pgo_graph {
+  pgo::Graph g;
+};

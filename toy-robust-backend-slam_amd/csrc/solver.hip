@@ -1,0 +1,849 @@
+// LM + block-Jacobi PCG driver of the pose-graph backend and the [gpu] part of the C-ABI.
+//
+// Replaces, for DCS-ceres/main.cpp METHOD 0/1 (paths relative to /root/reference/DCS-ceres):
+//   main.cpp:66-68,95-153   problem assembly  -> pgo_create (shard structure + device upload)
+//   main.cpp:154-163        ceres::Solve      -> pgo_solve / pgo_lm_begin + pgo_lm_step
+// The minimiser follows Ceres' TrustRegionMinimizer + LevenbergMarquardtStrategy defaults
+// (SURVEY.md R9); the linear solve is block-Jacobi PCG on the Jacobi-scaled normal equations.
+//
+// There is NO CPU fallback here: every [gpu] entry point fails with PGO_ERR_NO_DEVICE when no
+// gfx950 device is visible.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "comm.h"
+#include "kernels.hip.h"
+#include "pgo_internal.h"
+
+using pgo::fail;
+namespace dev = pgo::dev;
+
+#define HIPC(expr)                                                                       \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) return fail(PGO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+#define PGOC(expr)            \
+  do {                        \
+    int _s = (expr);          \
+    if (_s != PGO_OK) return _s; \
+  } while (0)
+
+static double wall_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+namespace {
+struct PartRef {
+  const double* p;
+  int n;
+  int is_max;
+};
+constexpr int N_SCAL = 16;
+constexpr int N_PART = 6;
+}  // namespace
+
+struct pgo_handle {
+  pgo_options opt;
+  pgo::ShardStructure S;
+  pgo_comm* comm = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+
+  int64_t n_full = 0;  // world * rows_per_rank  (>= N; tail rows are padding)
+  // graph
+  double *poses = nullptr, *cand = nullptr, *scale = nullptr;
+  int32_t *e_ia = nullptr, *e_ib = nullptr;
+  double *e_mx = nullptr, *e_my = nullptr, *e_mt = nullptr;
+  uint8_t* e_flags = nullptr;
+  double* jr = nullptr;
+  int32_t *inc_ptr = nullptr, *inc_edge = nullptr, *inc_col = nullptr, *tile_row = nullptr;
+  int64_t inc_stride = 0;
+  // normal equations
+  double *hoff = nullptr, *hd = nullptr, *gs = nullptr, *d2 = nullptr, *minv = nullptr;
+  // CG
+  double *y = nullptr, *r = nullptr, *z = nullptr, *ap = nullptr, *p_full = nullptr;
+  dev::CgState* st = nullptr;
+  dev::CgState* h_st = nullptr;  // pinned
+  // reductions
+  double* part[N_PART] = {nullptr};
+  int part_cap = 0;
+  double* scal = nullptr;
+  double* h_scal = nullptr;  // pinned
+  int* bad = nullptr;
+  // grids
+  int g_edge = 1, g_rows = 1, g_vec = 1, g_flat = 1, g_spmv = 1, g_asm = 1;
+
+  // LM state (TrustRegionMinimizer)
+  bool lm_active = false, lin_valid = false, lm_done = false;
+  int iter = 0, prev_success = 1, invalid_run = 0, successful = 0, total_pcg = 0, termination = 0;
+  double cost = 0, initial_cost = 0, radius = 0, decrease_factor = 2, x_norm = 0, gmax = 0;
+  double t_eval = 0, t_asm = 0, t_lin = 0, t_cand = 0, t_total = 0;
+  std::vector<pgo_iter_record> recs;
+
+  ~pgo_handle() {
+    if (device >= 0) (void)hipSetDevice(device);
+    for (void* p : allocs) (void)hipFree(p);
+    if (h_st) (void)hipHostFree(h_st);
+    if (h_scal) (void)hipHostFree(h_scal);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  template <class T>
+  int dalloc(T** out, int64_t n) {
+    void* p = nullptr;
+    size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(PGO_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    allocs.push_back(p);
+    e = hipMemsetAsync(p, 0, bytes, stream);
+    if (e != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    *out = (T*)p;
+    return PGO_OK;
+  }
+  template <class T>
+  int upload(T* dst, const std::vector<T>& src) {
+    if (src.empty()) return PGO_OK;
+    HIPC(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+    return PGO_OK;
+  }
+  int sync() {
+    HIPC(hipStreamSynchronize(stream));
+    return PGO_OK;
+  }
+  int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PGO_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return PGO_OK;
+  }
+
+  // ---- reductions to scalars: scal[first..first+k) = reduce(parts) [+ all-reduce], no host sync
+  int reduce_to_scal(std::initializer_list<PartRef> parts, int first, bool allreduce_max = false) {
+    dev::FinArgs F;
+    memset(&F, 0, sizeof F);
+    int k = 0;
+    for (const PartRef& pr : parts) {
+      F.part[k] = pr.p;
+      F.n[k] = pr.n;
+      F.is_max[k] = pr.is_max;
+      ++k;
+    }
+    F.count = k;
+    F.out = scal + first;
+    hipLaunchKernelGGL(dev::k_finalize, dim3(1), dim3(dev::WG), 0, stream, F);
+    PGOC(check_launch("k_finalize"));
+    if (comm && comm->world > 1) PGOC(comm->allreduce(scal + first, k, allreduce_max, stream));
+    return PGO_OK;
+  }
+  int fetch_scal(int first, int count) {
+    HIPC(hipMemcpyAsync(h_scal + first, scal + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, stream));
+    return sync();
+  }
+  int allgather(double* full) {
+    if (comm && comm->world > 1) PGOC(comm->allgather_inplace(full, (int64_t)3 * S.rows_per_rank, stream));
+    return PGO_OK;
+  }
+
+  // ---- K1
+  dev::EdgeArgs edge_args(const double* x, const double* sc, int apply_loss) const {
+    dev::EdgeArgs A;
+    A.poses = x;
+    A.scale = sc;
+    A.ia = e_ia;
+    A.ib = e_ib;
+    A.mx = e_mx;
+    A.my = e_my;
+    A.mt = e_mt;
+    A.flags = e_flags;
+    A.n_edges = S.n_edges_local;
+    A.apply_loss = apply_loss;
+    A.phi = opt.phi;
+    A.huber_delta = opt.huber_delta;
+    return A;
+  }
+  void launch_eval(const double* x, const double* sc, int apply_loss, bool with_jac) {
+    dev::EdgeArgs A = edge_args(x, sc, apply_loss);
+    if (with_jac) hipLaunchKernelGGL(dev::k_edge_eval<true>, dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
+    else hipLaunchKernelGGL(dev::k_edge_eval<false>, dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
+  }
+  // evaluates at x; on return h_scal[slot] = cost, h_scal[slot+1] = #bad flags (needs fetch by caller)
+  int eval_enqueue(const double* x, const double* sc, int apply_loss, bool with_jac, int slot) {
+    HIPC(hipMemsetAsync(bad, 0, sizeof(int), stream));
+    launch_eval(x, sc, apply_loss, with_jac);
+    PGOC(check_launch("k_edge_eval"));
+    // the flag rides along as a "partial array" of length 1 after conversion to double
+    hipLaunchKernelGGL(dev::k_flag_to_double, dim3(1), dim3(1), 0, stream, bad, part[4]);
+    return reduce_to_scal({{part[5], g_edge, 0}, {part[4], 1, 0}}, slot);
+  }
+
+  // ---- K2
+  dev::AsmArgs asm_args() const {
+    dev::AsmArgs A;
+    A.jr = jr;
+    A.inc_ptr = inc_ptr;
+    A.inc_edge = inc_edge;
+    A.tile_row = tile_row;
+    A.n_tiles = S.n_tiles();
+    A.n_loc = S.n_loc;
+    A.inc_stride = inc_stride;
+    A.hoff = hoff;
+    A.hd = hd;
+    A.gs = gs;
+    return A;
+  }
+  int assemble_enqueue() {
+    if (S.n_tiles() == 0) return PGO_OK;
+    hipLaunchKernelGGL(dev::k_assemble, dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
+    return check_launch("k_assemble");
+  }
+
+  // ---- K3
+  dev::SpmvArgs spmv_args(const double* p, double* yout, double* dot_part, int with_d2, const int32_t* done) const {
+    dev::SpmvArgs A;
+    A.inc_ptr = inc_ptr;
+    A.inc_col = inc_col;
+    A.tile_row = tile_row;
+    A.n_tiles = S.n_tiles();
+    A.n_loc = S.n_loc;
+    A.lo = S.lo;
+    A.with_d2 = with_d2;
+    A.inc_stride = inc_stride;
+    A.hoff = hoff;
+    A.hd = hd;
+    A.d2 = d2;
+    A.p = p;
+    A.y = yout;
+    A.dot_part = dot_part;
+    A.done = done;
+    return A;
+  }
+  int spmv_enqueue(const double* p, double* yout, double* dot_part, int with_d2, const int32_t* done) {
+    hipLaunchKernelGGL(dev::k_spmv, dim3(g_spmv), dim3(dev::WG), 0, stream, spmv_args(p, yout, dot_part, with_d2, done));
+    return check_launch("k_spmv");
+  }
+
+  dev::CgVec cg_vec() const {
+    dev::CgVec V;
+    V.n_loc = S.n_loc;
+    V.lo = S.lo;
+    V.minv = minv;
+    V.y = y;
+    V.r = r;
+    V.z = z;
+    V.ap = ap;
+    V.p = p_full;
+    V.st = st;
+    return V;
+  }
+
+  int create(int32_t N, const double* poses_h, int32_t E, const int32_t* ia, const int32_t* ib, const double* meas,
+             const uint8_t* kind);
+  int linearize(bool first);
+  int lm_begin();
+  int lm_iteration(bool* stop);
+  int pcg(int* iters, double* rel);
+  void fill_summary(pgo_summary* s) const;
+};
+
+// --------------------------------------------------------------------- create
+int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_t* ia, const int32_t* ib,
+                       const double* meas, const uint8_t* kind) {
+  const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+  PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, &S));
+  HIPC(hipSetDevice(device));
+  HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  n_full = (int64_t)world * S.rows_per_rank;
+  const int64_t EL = S.n_edges_local, NL = S.n_loc;
+  inc_stride = ((S.n_inc + 1) / 2) * 2;  // keep planes 16-byte aligned
+  if (inc_stride == 0) inc_stride = 2;
+
+  PGOC(dalloc(&poses, 3 * n_full));
+  PGOC(dalloc(&cand, 3 * n_full));
+  PGOC(dalloc(&scale, 3 * n_full));
+  PGOC(dalloc(&p_full, 3 * n_full));
+  PGOC(dalloc(&e_ia, EL));
+  PGOC(dalloc(&e_ib, EL));
+  PGOC(dalloc(&e_mx, EL));
+  PGOC(dalloc(&e_my, EL));
+  PGOC(dalloc(&e_mt, EL));
+  PGOC(dalloc(&e_flags, EL));
+  PGOC(dalloc(&jr, EL * dev::REC));
+  PGOC(dalloc(&inc_ptr, NL + 1));
+  PGOC(dalloc(&inc_edge, S.n_inc));
+  PGOC(dalloc(&inc_col, S.n_inc));
+  PGOC(dalloc(&tile_row, (int64_t)S.tile_row.size()));
+  PGOC(dalloc(&hoff, 9 * inc_stride));
+  PGOC(dalloc(&hd, 6 * NL));
+  PGOC(dalloc(&gs, 3 * NL));
+  PGOC(dalloc(&d2, 3 * NL));
+  PGOC(dalloc(&minv, 6 * NL));
+  PGOC(dalloc(&y, 3 * NL));
+  PGOC(dalloc(&r, 3 * NL));
+  PGOC(dalloc(&z, 3 * NL));
+  PGOC(dalloc(&ap, 3 * NL));
+  PGOC(dalloc(&st, 1));
+  PGOC(dalloc(&scal, N_SCAL));
+  PGOC(dalloc(&bad, 1));
+  HIPC(hipHostMalloc((void**)&h_st, sizeof(dev::CgState)));
+  HIPC(hipHostMalloc((void**)&h_scal, N_SCAL * sizeof(double)));
+
+  auto cdiv = [](int64_t a, int64_t b) { return (int)((a + b - 1) / b); };
+  g_edge = std::max(1, cdiv(EL, dev::WG));
+  g_rows = std::max(1, cdiv(NL, dev::WG));
+  g_vec = std::min(std::max(1, cdiv(NL, dev::WG)), 1024);
+  g_flat = std::min(std::max(1, cdiv(3 * NL, dev::WG)), 2048);
+  g_spmv = std::min(std::max(1, S.n_tiles()), 2048);
+  g_asm = std::min(std::max(1, S.n_tiles()), 1 << 20);
+  part_cap = std::max(g_edge, 2048);
+  for (int k = 0; k < N_PART; ++k) PGOC(dalloc(&part[k], part_cap));
+
+  HIPC(hipMemcpyAsync(poses, poses_h, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, stream));
+  PGOC(upload(e_ia, S.ia));
+  PGOC(upload(e_ib, S.ib));
+  PGOC(upload(e_mx, S.mx));
+  PGOC(upload(e_my, S.my));
+  PGOC(upload(e_mt, S.mt));
+  PGOC(upload(e_flags, S.flags));
+  PGOC(upload(inc_ptr, S.inc_ptr));
+  PGOC(upload(inc_edge, S.inc_edge));
+  PGOC(upload(inc_col, S.inc_col));
+  PGOC(upload(tile_row, S.tile_row));
+  return sync();
+}
+
+// evaluate + assemble at `poses` with the current `scale`; leaves cost/bad in h_scal[0..1]
+int pgo_handle::linearize(bool /*first*/) {
+  double t0 = wall_s();
+  PGOC(eval_enqueue(poses, scale, 1, true, 0));
+  PGOC(fetch_scal(0, 2));
+  t_eval += wall_s() - t0;
+  if (h_scal[1] > 0.0 || !std::isfinite(h_scal[0])) return fail(PGO_ERR_NUMERIC, "residual/Jacobian evaluation produced non-finite values");
+  t0 = wall_s();
+  PGOC(assemble_enqueue());
+  PGOC(sync());
+  t_asm += wall_s() - t0;
+  return PGO_OK;
+}
+
+int pgo_handle::lm_begin() {
+  HIPC(hipSetDevice(device));
+  lm_active = true;
+  lm_done = false;
+  iter = 0;
+  prev_success = 1;
+  invalid_run = 0;
+  successful = 0;
+  total_pcg = 0;
+  termination = 0;
+  radius = opt.radius0;
+  decrease_factor = 2.0;
+  t_eval = t_asm = t_lin = t_cand = 0;
+  recs.clear();
+  const double t_begin = wall_s();
+  t_total = 0;
+  const int fixed = opt.fixed_pose;
+  // pass 1: unit scales (0 on the constant pose) -> column norms for Jacobi scaling
+  hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 0, scale);
+  PGOC(check_launch("k_jacobi_scale"));
+  PGOC(allgather(scale));
+  PGOC(linearize(true));
+  if (opt.jacobi_scaling) {
+    hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 1, scale);
+    PGOC(check_launch("k_jacobi_scale"));
+    PGOC(allgather(scale));
+    PGOC(linearize(false));
+  }
+  cost = initial_cost = h_scal[0];
+  hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
+  PGOC(check_launch("k_grad_max"));
+  PGOC(reduce_to_scal({{part[0], g_flat, 1}}, 2, true));
+  hipLaunchKernelGGL(dev::k_xnorm, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, poses, scale, part[1]);
+  PGOC(check_launch("k_xnorm"));
+  PGOC(reduce_to_scal({{part[1], g_flat, 0}}, 3));
+  PGOC(fetch_scal(2, 2));
+  gmax = h_scal[2];
+  x_norm = std::sqrt(h_scal[3]);
+  lin_valid = true;
+  pgo_iter_record R;
+  memset(&R, 0, sizeof R);
+  R.iter = 0;
+  R.step_ok = 1;
+  R.cost = cost;
+  R.gradient_max_norm = gmax;
+  R.radius = radius;
+  R.seconds = wall_s() - t_begin;
+  t_total += R.seconds;
+  recs.push_back(R);
+  if (opt.verbose) {
+    printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  pcg_it  pcg_rel\n");
+    printf("%4d % .6e  % .2e  % .2e  % .2e  % .2e  % .2e  %6d  %.1e\n", 0, cost, 0.0, gmax, 0.0, 0.0, radius, 0, 0.0);
+  }
+  return PGO_OK;
+}
+
+// block-Jacobi PCG on (H + D2) y = gs, y0 = 0.  Host checks the residual every
+// pcg_check_every iterations; in between the kernels early-out on st->done.
+int pgo_handle::pcg(int* iters, double* rel) {
+  dev::CgVec V = cg_vec();
+  const bool multi = comm && comm->world > 1;
+  hipLaunchKernelGGL(dev::k_cg_init, dim3(g_vec), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
+  PGOC(check_launch("k_cg_init"));
+  PGOC(reduce_to_scal({{part[0], g_vec, 0}, {part[1], g_vec, 0}}, 4));
+  hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
+  PGOC(check_launch("k_cg_init_fin"));
+  PGOC(allgather(p_full));
+  const int max_it = std::max(0, opt.pcg_max_iters);
+  const int every = std::max(1, opt.pcg_check_every);
+  int it = 0;
+  while (true) {
+    const int chunk = std::min(every, max_it - it);
+    for (int c = 0; c < chunk; ++c) {
+      const int par = (it + c) & 1;
+      PGOC(spmv_enqueue(p_full, ap, part[0], 1, &st->done));
+      if (multi) {
+        PGOC(reduce_to_scal({{part[0], g_spmv, 0}}, 6));
+        hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, scal + 6, 1, part[1], part[2]);
+        PGOC(check_launch("k_cg_update1"));
+        PGOC(reduce_to_scal({{part[1], g_vec, 0}, {part[2], g_vec, 0}}, 7));
+        hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
+        PGOC(check_launch("k_cg_update2"));
+        PGOC(allgather(p_full));
+      } else {
+        hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, part[0], g_spmv, part[1], part[2]);
+        hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_vec, part[2], g_vec);
+        PGOC(check_launch("k_cg_update"));
+      }
+    }
+    it += chunk;
+    HIPC(hipMemcpyAsync(h_st, st, sizeof(dev::CgState), hipMemcpyDeviceToHost, stream));
+    PGOC(sync());
+    if (h_st->done || it >= max_it) break;
+  }
+  *iters = h_st->iters;
+  *rel = (h_st->bb > 0.0) ? std::sqrt(h_st->rr / h_st->bb) : 0.0;
+  return PGO_OK;
+}
+
+// one TrustRegionMinimizer iteration.  *stop is set when a termination test fires.
+int pgo_handle::lm_iteration(bool* stop) {
+  *stop = false;
+  // FinalizeIterationAndCheckIfMinimizerCanContinue
+  if (iter >= opt.max_iters) {
+    termination = PGO_TERM_NO_CONVERGENCE;
+    *stop = true;
+    return PGO_OK;
+  }
+  if (prev_success && gmax <= opt.gtol) {
+    termination = PGO_TERM_CONVERGENCE_GTOL;
+    *stop = true;
+    return PGO_OK;
+  }
+  if (radius < opt.min_radius) {
+    termination = PGO_TERM_MIN_RADIUS;
+    *stop = true;
+    return PGO_OK;
+  }
+  const double it0 = wall_s();
+  ++iter;
+  pgo_iter_record R;
+  memset(&R, 0, sizeof R);
+  R.iter = iter;
+  const bool multi = comm && comm->world > 1;
+
+  // LM diagonal + preconditioner, then the linear solve
+  double t0 = wall_s();
+  hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, opt.fixed_pose, radius,
+                     opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv);
+  PGOC(check_launch("k_prepare"));
+  int k_it = 0;
+  double rel = 0.0;
+  PGOC(pcg(&k_it, &rel));
+  total_pcg += k_it;
+  R.pcg_iters = k_it;
+  R.pcg_rel_residual = rel;
+  // model_cost_change = -(J d).(r + J d / 2), d = -S y   ==   y.gs - y.(H y) / 2
+  hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
+  PGOC(check_launch("k_scatter_owned"));
+  PGOC(allgather(p_full));
+  PGOC(spmv_enqueue(p_full, ap, part[0], 0, nullptr));  // part[0] <- partials of y.(H y)
+  hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs, part[1]);
+  PGOC(check_launch("k_dot"));
+  // candidate x + d and |d|^2
+  double* x_old = poses;
+  hipLaunchKernelGGL(dev::k_candidate, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, x_old, scale, y, cand, part[3]);
+  PGOC(check_launch("k_candidate"));
+  PGOC(reduce_to_scal({{part[1], g_flat, 0}, {part[0], g_spmv, 0}, {part[3], g_flat, 0}}, 0));
+  PGOC(fetch_scal(0, 3));
+  t_lin += wall_s() - t0;
+  const double ydotg = h_scal[0], yHy = h_scal[1], step2 = h_scal[2];
+  const double model = ydotg - 0.5 * yHy;
+  (void)multi;
+  if (!std::isfinite(model) || !std::isfinite(step2) || !(model > 0.0)) {  // invalid step
+    if (++invalid_run >= 5) {
+      termination = PGO_TERM_FAILURE;
+      *stop = true;
+      return PGO_OK;
+    }
+    radius /= decrease_factor;
+    decrease_factor *= 2.0;
+    prev_success = 0;
+    R.step_ok = -1;
+    R.cost = cost;
+    R.radius = radius;
+    R.gradient_max_norm = gmax;
+    R.seconds = wall_s() - it0;
+    t_total += R.seconds;
+    recs.push_back(R);
+    return PGO_OK;
+  }
+  invalid_run = 0;
+  t0 = wall_s();
+  PGOC(allgather(cand));
+  PGOC(eval_enqueue(cand, nullptr, 1, false, 0));
+  PGOC(fetch_scal(0, 2));
+  t_cand += wall_s() - t0;
+  double cand_cost = h_scal[0];
+  if (h_scal[1] > 0.0 || !std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+  R.step_norm = std::sqrt(step2);
+  R.cost_change = cost - cand_cost;
+  R.gradient_max_norm = gmax;
+  auto finish = [&](int term) {
+    termination = term;
+    R.cost = cost;
+    R.radius = radius;
+    R.seconds = wall_s() - it0;
+    t_total += R.seconds;
+    recs.push_back(R);
+    *stop = true;
+  };
+  if (R.step_norm <= opt.ptol * (x_norm + opt.ptol)) {  // ParameterToleranceReached
+    finish(PGO_TERM_CONVERGENCE_PTOL);
+    return PGO_OK;
+  }
+  if (std::fabs(R.cost_change) <= opt.ftol * cost) {  // FunctionToleranceReached
+    finish(PGO_TERM_CONVERGENCE_FTOL);
+    return PGO_OK;
+  }
+  const double rho = (cand_cost >= std::numeric_limits<double>::max()) ? -std::numeric_limits<double>::max() : R.cost_change / model;
+  R.relative_decrease = rho;
+  if (rho > opt.min_relative_decrease) {  // HandleSuccessfulStep
+    std::swap(poses, cand);
+    hipLaunchKernelGGL(dev::k_xnorm, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, poses, scale, part[1]);
+    PGOC(check_launch("k_xnorm"));
+    PGOC(reduce_to_scal({{part[1], g_flat, 0}}, 3));
+    int st_lin = linearize(false);
+    if (st_lin == PGO_ERR_NUMERIC) {
+      finish(PGO_TERM_FAILURE);
+      return PGO_OK;
+    }
+    PGOC(st_lin);
+    cost = h_scal[0];
+    hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
+    PGOC(check_launch("k_grad_max"));
+    PGOC(reduce_to_scal({{part[0], g_flat, 1}}, 2, true));
+    PGOC(fetch_scal(2, 2));
+    gmax = h_scal[2];
+    x_norm = std::sqrt(h_scal[3]);
+    const double t = 2.0 * rho - 1.0;
+    radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+    radius = std::min(opt.max_radius, radius);
+    decrease_factor = 2.0;
+    prev_success = 1;
+    ++successful;
+    R.step_ok = 1;
+    R.cost = cost;
+    R.gradient_max_norm = gmax;
+  } else {  // HandleUnsuccessfulStep
+    radius /= decrease_factor;
+    decrease_factor *= 2.0;
+    prev_success = 0;
+    R.step_ok = 0;
+    R.cost = cand_cost;
+  }
+  R.radius = radius;
+  R.seconds = wall_s() - it0;
+  t_total += R.seconds;
+  recs.push_back(R);
+  if (opt.verbose)
+    printf("%4d % .6e  % .2e  % .2e  % .2e  % .2e  % .2e  %6d  %.1e\n", iter, R.cost, R.cost_change, gmax, R.step_norm, rho,
+           radius, k_it, rel);
+  return PGO_OK;
+}
+
+void pgo_handle::fill_summary(pgo_summary* s) const {
+  if (!s) return;
+  memset(s, 0, sizeof *s);
+  s->termination = termination;
+  s->iterations = iter;
+  s->successful_steps = successful;
+  s->total_pcg_iters = total_pcg;
+  s->initial_cost = initial_cost;
+  s->final_cost = cost;
+  s->seconds_total = t_total;
+  s->seconds_eval = t_eval;
+  s->seconds_assemble = t_asm;
+  s->seconds_linear = t_lin;
+  s->seconds_candidate = t_cand;
+}
+
+// ====================================================================== C-ABI
+static int require_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(PGO_ERR_NO_DEVICE, "no HIP device visible (this backend has no CPU path)");
+  if (device < 0 || device >= n) return fail(PGO_ERR_INVALID_ARG, "device index out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(PGO_ERR_HIP, "hipGetDeviceProperties");
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(PGO_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  return PGO_OK;
+}
+
+extern "C" {
+
+void pgo_options_default(pgo_options* o) {
+  if (!o) return;
+  memset(o, 0, sizeof *o);
+  o->method = 1;
+  o->max_iters = 50;
+  o->fixed_pose = 0;
+  o->jacobi_scaling = 1;
+  o->phi = 0.5;
+  o->huber_delta = 0.01;
+  o->ftol = 1e-6;
+  o->gtol = 1e-10;
+  o->ptol = 1e-8;
+  o->radius0 = 1e4;
+  o->max_radius = 1e16;
+  o->min_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->pcg_rtol = 1e-10;
+  o->pcg_max_iters = 50000;
+  o->pcg_check_every = 50;
+  o->verbose = 0;
+  o->use_graphs = 0;
+}
+
+int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
+               const double* meas, const uint8_t* kind, const pgo_options* opt, pgo_comm* comm, int device) {
+  if (!h || !poses || n_poses <= 0 || n_edges < 0 || (n_edges && (!ia || !ib || !meas || !kind)))
+    return fail(PGO_ERR_INVALID_ARG, "pgo_create: bad argument");
+  pgo_options o;
+  if (opt) o = *opt;
+  else pgo_options_default(&o);
+  if (o.method != 0 && o.method != 1)
+    return fail(PGO_ERR_UNSUPPORTED, "only METHOD 0 (plain) and 1 (DCS) are implemented (reference main.cpp:54-56)");
+  if (o.fixed_pose >= n_poses) return fail(PGO_ERR_INVALID_ARG, "fixed_pose out of range");
+  PGOC(require_device(device));
+  std::unique_ptr<pgo_handle> H(new pgo_handle);
+  H->opt = o;
+  H->comm = comm;
+  H->device = device;
+  PGOC(H->create(n_poses, poses, n_edges, ia, ib, meas, kind));
+  *h = H.release();
+  return PGO_OK;
+}
+
+int pgo_create_from_graph(pgo_t** h, const pgo_graph* g, const pgo_options* opt, pgo_comm* comm, int device) {
+  if (!g) return fail(PGO_ERR_INVALID_ARG, "pgo_create_from_graph: null graph");
+  const pgo::Graph& G = g->g;
+  return pgo_create(h, G.n_poses(), G.pose.data(), G.n_edges(), G.ea.data(), G.eb.data(), G.meas.data(), G.kind.data(), opt,
+                    comm, device);
+}
+
+void pgo_destroy(pgo_t* h) { delete h; }
+
+int pgo_set_poses(pgo_t* h, const double* poses) {
+  if (!h || !poses) return fail(PGO_ERR_INVALID_ARG, "pgo_set_poses: null");
+  HIPC(hipSetDevice(h->device));
+  HIPC(hipMemcpyAsync(h->poses, poses, (size_t)3 * h->S.n_poses * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  h->lin_valid = false;
+  h->lm_active = false;
+  return h->sync();
+}
+
+int pgo_get_poses(pgo_t* h, double* out) {
+  if (!h || !out) return fail(PGO_ERR_INVALID_ARG, "pgo_get_poses: null");
+  HIPC(hipSetDevice(h->device));
+  HIPC(hipMemcpyAsync(out, h->poses, (size_t)3 * h->S.n_poses * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return h->sync();
+}
+
+int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss, double* cost, double* r_out, double* J_out) {
+  if (!h) return fail(PGO_ERR_INVALID_ARG, "pgo_eval: null handle");
+  HIPC(hipSetDevice(h->device));
+  const bool want_jac = r_out || J_out;
+  if (want_jac && h->comm && h->comm->world > 1) return fail(PGO_ERR_UNSUPPORTED, "pgo_eval: r/J outputs need world == 1");
+  const double* x = h->poses;
+  if (poses_or_null) {
+    HIPC(hipMemcpyAsync(h->cand, poses_or_null, (size_t)3 * h->S.n_poses * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    x = h->cand;
+  }
+  if (want_jac) {
+    h->lin_valid = false;  // the record buffer is about to be overwritten
+    h->lm_active = false;
+  }
+  PGOC(h->eval_enqueue(x, nullptr, apply_loss, want_jac, 0));
+  PGOC(h->fetch_scal(0, 2));
+  if (cost) *cost = h->h_scal[0];
+  if (want_jac) {
+    const int64_t EL = h->S.n_edges_local;
+    std::vector<double> rec((size_t)EL * dev::REC);
+    HIPC(hipMemcpyAsync(rec.data(), h->jr, rec.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    PGOC(h->sync());
+    for (int64_t k = 0; k < EL; ++k) {
+      const int64_t e = h->S.orig_edge[k];
+      const double* R = &rec[(size_t)k * dev::REC];
+      if (J_out) memcpy(J_out + 18 * e, R, 18 * sizeof(double));
+      if (r_out) memcpy(r_out + 3 * e, R + 18, 3 * sizeof(double));
+    }
+  }
+  if (h->h_scal[1] > 0.0) return fail(PGO_ERR_NUMERIC, "non-finite residual or Jacobian");
+  return PGO_OK;
+}
+
+int pgo_lm_begin(pgo_t* h) {
+  if (!h) return fail(PGO_ERR_INVALID_ARG, "pgo_lm_begin: null handle");
+  return h->lm_begin();
+}
+
+int pgo_lm_step(pgo_t* h, int32_t n_iters, int32_t* done, pgo_summary* s) {
+  if (!h) return fail(PGO_ERR_INVALID_ARG, "pgo_lm_step: null handle");
+  if (!h->lm_active || !h->lin_valid) return fail(PGO_ERR_INVALID_ARG, "pgo_lm_step: call pgo_lm_begin first");
+  HIPC(hipSetDevice(h->device));
+  bool stop = h->lm_done;
+  for (int32_t k = 0; k < n_iters && !stop; ++k) PGOC(h->lm_iteration(&stop));
+  h->lm_done = stop;
+  if (done) *done = stop ? 1 : 0;
+  h->fill_summary(s);
+  return PGO_OK;
+}
+
+int pgo_solve(pgo_t* h, pgo_summary* s) {
+  if (!h) return fail(PGO_ERR_INVALID_ARG, "pgo_solve: null handle");
+  PGOC(h->lm_begin());
+  bool stop = false;
+  while (!stop) PGOC(h->lm_iteration(&stop));
+  h->lm_done = true;
+  h->fill_summary(s);
+  return PGO_OK;
+}
+
+int32_t pgo_num_iter_records(const pgo_t* h) { return h ? (int32_t)h->recs.size() : 0; }
+int pgo_get_iter_records(const pgo_t* h, pgo_iter_record* out, int32_t cap) {
+  if (!h || !out) return fail(PGO_ERR_INVALID_ARG, "pgo_get_iter_records: null");
+  int32_t n = std::min<int32_t>(cap, (int32_t)h->recs.size());
+  memcpy(out, h->recs.data(), (size_t)n * sizeof(pgo_iter_record));
+  return PGO_OK;
+}
+
+// ------------------------------------------------------------ debug / bench
+int pgo_debug_normal_eq(pgo_t* h, double* g_out, double* hdiag_out) {
+  if (!h) return fail(PGO_ERR_INVALID_ARG, "pgo_debug_normal_eq: null handle");
+  if (h->comm && h->comm->world > 1) return fail(PGO_ERR_UNSUPPORTED, "world == 1 only");
+  HIPC(hipSetDevice(h->device));
+  h->lm_active = false;
+  hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(h->g_rows), dim3(dev::WG), 0, h->stream, h->hd, h->S.n_loc, h->S.lo,
+                     h->opt.fixed_pose, 0, h->scale);
+  PGOC(h->check_launch("k_jacobi_scale"));
+  int st = h->linearize(true);
+  h->lin_valid = false;
+  PGOC(st);
+  const int64_t N = h->S.n_loc;
+  if (g_out) HIPC(hipMemcpyAsync(g_out, h->gs, (size_t)3 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> planes;
+  if (hdiag_out) {
+    planes.resize((size_t)6 * N);
+    HIPC(hipMemcpyAsync(planes.data(), h->hd, planes.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  PGOC(h->sync());
+  if (hdiag_out) {
+    static const int map9[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    for (int64_t i = 0; i < N; ++i)
+      for (int c = 0; c < 9; ++c) hdiag_out[9 * i + c] = planes[(size_t)map9[c] * N + i];
+  }
+  return PGO_OK;
+}
+
+int pgo_debug_spmv(pgo_t* h, const double* x, double* yout) {
+  if (!h || !x || !yout) return fail(PGO_ERR_INVALID_ARG, "pgo_debug_spmv: null");
+  if (h->comm && h->comm->world > 1) return fail(PGO_ERR_UNSUPPORTED, "world == 1 only");
+  HIPC(hipSetDevice(h->device));
+  const int64_t N = h->S.n_poses;
+  HIPC(hipMemcpyAsync(h->p_full, x, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  PGOC(h->spmv_enqueue(h->p_full, h->ap, h->part[0], 0, nullptr));
+  HIPC(hipMemcpyAsync(yout, h->ap, (size_t)3 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return h->sync();
+}
+
+static int time_launches(pgo_handle* h, int reps, const std::function<void()>& launch, double* ms_avg) {
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0));
+  HIPC(hipEventCreate(&e1));
+  launch();  // one untimed launch
+  HIPC(hipEventRecord(e0, h->stream));
+  for (int i = 0; i < reps; ++i) launch();
+  HIPC(hipEventRecord(e1, h->stream));
+  HIPC(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPC(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_avg = (double)ms / reps;
+  return h->check_launch("bench launch");
+}
+
+int pgo_bench_eval(pgo_t* h, int reps, int with_jacobian, pgo_kernel_stats* out) {
+  if (!h || !out || reps < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_eval: bad argument");
+  HIPC(hipSetDevice(h->device));
+  if (with_jacobian && !h->lin_valid) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_eval: call pgo_lm_begin first (needs the scale vector)");
+  double ms = 0;
+  PGOC(time_launches(h, reps, [&] { h->launch_eval(h->poses, with_jacobian ? h->scale : nullptr, 1, with_jacobian != 0); }, &ms));
+  out->ms_avg = ms;
+  out->units = h->S.n_edges_local;
+  // 84 B read + 176 B written per edge with the Jacobian; 84 + 8 without
+  out->algorithmic_bytes = (double)h->S.n_edges_local * (with_jacobian ? 260.0 : 92.0);
+  return PGO_OK;
+}
+
+int pgo_bench_assemble(pgo_t* h, int reps, pgo_kernel_stats* out) {
+  if (!h || !out || reps < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_assemble: bad argument");
+  if (!h->lin_valid) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_assemble: call pgo_lm_begin first");
+  HIPC(hipSetDevice(h->device));
+  double ms = 0;
+  PGOC(time_launches(h, reps, [&] { (void)h->assemble_enqueue(); }, &ms));
+  out->ms_avg = ms;
+  out->units = h->S.n_edges_local;
+  // every record read once (176 B/edge); per incidence 4 B index + 72 B block written; per row 72 B out + 4 B pointer
+  out->algorithmic_bytes = 176.0 * h->S.n_edges_local + 76.0 * (double)h->S.n_inc + 76.0 * h->S.n_loc;
+  return PGO_OK;
+}
+
+int pgo_bench_spmv(pgo_t* h, int reps, pgo_kernel_stats* out) {
+  if (!h || !out || reps < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_spmv: bad argument");
+  if (!h->lin_valid) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_spmv: call pgo_lm_begin first");
+  HIPC(hipSetDevice(h->device));
+  double ms = 0;
+  PGOC(time_launches(h, reps, [&] { (void)h->spmv_enqueue(h->p_full, h->ap, h->part[0], 1, nullptr); }, &ms));
+  out->ms_avg = ms;
+  out->units = h->S.n_inc + h->S.n_loc;
+  // 76 B per off-diagonal block (value + column) ; per row: 48 B diagonal planes + 24 B D'D + 4 B row
+  // pointer + 24 B y + 24 B p
+  out->algorithmic_bytes = 76.0 * (double)h->S.n_inc + 124.0 * h->S.n_loc;
+  return PGO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// Symbolic phase, host side, once per graph: which rows of J'J a rank owns, which
+// edges it must evaluate, the row -> incidence lists that drive the assembly and
+// SpMV kernels, and the tiling of rows into workgroup-sized pieces.
+//
+// Sharding rule (north_star: "shards by pose-id range"):
+//   rank r owns rows [r*rpr, min(N,(r+1)*rpr)), rpr = ceil(N/world).
+//   A rank evaluates EVERY edge touching one of its rows (cut edges are evaluated
+//   on both owners - 85 bytes of input per edge - instead of exchanging 176-byte
+//   Jacobian records), so assembly needs no communication at all.  An edge's cost
+//   is counted on the rank that owns its first endpoint Edge::a.
+#include <algorithm>
+#include <numeric>
+
+#include "pgo_internal.h"
+
+namespace pgo {
+
+int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t* ib, const double* meas,
+                          const uint8_t* kind, int method, int world, int rank, ShardStructure* S) {
+  if (N <= 0 || E < 0 || world < 1 || rank < 0 || rank >= world)
+    return fail(PGO_ERR_INVALID_ARG, "build_shard_structure: bad sizes");
+  for (int32_t e = 0; e < E; ++e) {
+    if (ia[e] < 0 || ia[e] >= N || ib[e] < 0 || ib[e] >= N)
+      return fail(PGO_ERR_INVALID_ARG, "edge " + std::to_string(e) + ": endpoint out of range");
+    if (ia[e] == ib[e])
+      return fail(PGO_ERR_INVALID_ARG, "edge " + std::to_string(e) + ": self loop (Ceres rejects duplicate parameter blocks)");
+  }
+  S->n_poses = N;
+  S->world = world;
+  S->rank = rank;
+  S->rows_per_rank = (N + world - 1) / world;
+  S->lo = std::min<int64_t>((int64_t)rank * S->rows_per_rank, N);
+  S->hi = std::min<int64_t>((int64_t)(rank + 1) * S->rows_per_rank, N);
+  S->n_loc = S->hi - S->lo;
+  const int32_t lo = S->lo, hi = S->hi;
+  auto owned = [&](int32_t p) { return p >= lo && p < hi; };
+
+  // local edges, sorted by (min endpoint, max endpoint, original index): pose
+  // gathers of consecutive lanes then walk the pose array almost sequentially
+  std::vector<int32_t> loc;
+  loc.reserve(world == 1 ? E : (size_t)(2.2 * E / world) + 16);
+  for (int32_t e = 0; e < E; ++e)
+    if (owned(ia[e]) || owned(ib[e])) loc.push_back(e);
+  std::sort(loc.begin(), loc.end(), [&](int32_t x, int32_t y) {
+    int32_t xm = std::min(ia[x], ib[x]), ym = std::min(ia[y], ib[y]);
+    if (xm != ym) return xm < ym;
+    int32_t xM = std::max(ia[x], ib[x]), yM = std::max(ia[y], ib[y]);
+    if (xM != yM) return xM < yM;
+    return x < y;
+  });
+  const int32_t EL = (int32_t)loc.size();
+  S->n_edges_local = EL;
+  S->orig_edge = loc;
+  S->ia.resize(EL);
+  S->ib.resize(EL);
+  S->mx.resize(EL);
+  S->my.resize(EL);
+  S->mt.resize(EL);
+  S->flags.resize(EL);
+  S->n_cut = 0;
+  for (int32_t k = 0; k < EL; ++k) {
+    int32_t e = loc[k];
+    S->ia[k] = ia[e];
+    S->ib[k] = ib[e];
+    S->mx[k] = meas[3 * (size_t)e + 0];
+    S->my[k] = meas[3 * (size_t)e + 1];
+    S->mt[k] = meas[3 * (size_t)e + 2];
+    // DCS on closure + bogus edges only when METHOD == 1 (reference main.cpp:112-114,135-137)
+    uint8_t f = (method == 1 && kind[e] != PGO_EDGE_ODOMETRY) ? 1 : 0;
+    if (owned(ia[e])) f |= 2;
+    S->flags[k] = f;
+    if (!(owned(ia[e]) && owned(ib[e]))) S->n_cut++;
+  }
+
+  // incidences of owned rows
+  std::vector<int32_t>& ptr = S->inc_ptr;
+  ptr.assign((size_t)S->n_loc + 1, 0);
+  for (int32_t k = 0; k < EL; ++k) {
+    if (owned(S->ia[k])) ptr[S->ia[k] - lo + 1]++;
+    if (owned(S->ib[k])) ptr[S->ib[k] - lo + 1]++;
+  }
+  for (int32_t i = 0; i < S->n_loc; ++i) ptr[i + 1] += ptr[i];
+  S->n_inc = ptr[S->n_loc];
+  S->inc_edge.resize(S->n_inc);
+  S->inc_col.resize(S->n_inc);
+  {
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    // local edges are visited in sorted order, so each row's incidences come out
+    // ordered by (min, max) endpoint, i.e. by column for the b-side and the a-side
+    for (int32_t k = 0; k < EL; ++k) {
+      int32_t a = S->ia[k], b = S->ib[k];
+      if (owned(a)) {
+        int32_t q = fill[a - lo]++;
+        S->inc_edge[q] = (k << 1) | 0;
+        S->inc_col[q] = b;
+      }
+      if (owned(b)) {
+        int32_t q = fill[b - lo]++;
+        S->inc_edge[q] = (k << 1) | 1;
+        S->inc_col[q] = a;
+      }
+    }
+    // order each row's incidences by column (deterministic accumulation order
+    // that does not depend on the sharding)
+    for (int32_t i = 0; i < S->n_loc; ++i) {
+      int32_t b = ptr[i], e = ptr[i + 1];
+      if (e - b < 2) continue;
+      std::vector<std::pair<int32_t, int32_t>> tmp(e - b);
+      for (int32_t q = b; q < e; ++q) tmp[q - b] = {S->inc_col[q], S->inc_edge[q]};
+      std::sort(tmp.begin(), tmp.end(), [&](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) {
+        if (x.first != y.first) return x.first < y.first;
+        // duplicates of one pair: order by the caller's edge index
+        return S->orig_edge[x.second >> 1] < S->orig_edge[y.second >> 1];
+      });
+      for (int32_t q = b; q < e; ++q) {
+        S->inc_col[q] = tmp[q - b].first;
+        S->inc_edge[q] = tmp[q - b].second;
+      }
+    }
+  }
+
+  // tiles
+  S->tile_row.clear();
+  S->tile_row.push_back(0);
+  int32_t row = 0;
+  while (row < S->n_loc) {
+    int32_t begin = row;
+    int64_t inc0 = ptr[row];
+    // at least one row per tile; more while their incidences fit one chunk
+    ++row;
+    while (row < S->n_loc && ptr[row + 1] - inc0 <= TILE_INC && row - begin < TILE_INC) ++row;
+    S->tile_row.push_back(row);
+  }
+  if (S->n_loc == 0) S->tile_row.assign(1, 0);
+  return PGO_OK;
+}
+
+}  // namespace pgo
+
+extern "C" int pgo_shard_plan(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int world,
+                              int rank, int32_t* lo, int32_t* hi, int32_t* n_local_edges, int32_t* n_cut_edges) {
+  if (n_poses <= 0 || n_edges < 0 || world < 1 || rank < 0 || rank >= world || (n_edges && (!ia || !ib)))
+    return pgo::fail(PGO_ERR_INVALID_ARG, "pgo_shard_plan: bad argument");
+  int32_t rpr = (n_poses + world - 1) / world;
+  int64_t l = std::min<int64_t>((int64_t)rank * rpr, n_poses), h = std::min<int64_t>((int64_t)(rank + 1) * rpr, n_poses);
+  int32_t nl = 0, nc = 0;
+  for (int32_t e = 0; e < n_edges; ++e) {
+    bool oa = ia[e] >= l && ia[e] < h, ob = ib[e] >= l && ib[e] < h;
+    if (oa || ob) {
+      ++nl;
+      if (!(oa && ob)) ++nc;
+    }
+  }
+  if (lo) *lo = (int32_t)l;
+  if (hi) *hi = (int32_t)h;
+  if (n_local_edges) *n_local_edges = nl;
+  if (n_cut_edges) *n_cut_edges = nc;
+  return PGO_OK;
+}
