@@ -1,0 +1,217 @@
+"""CPU: host-side logic of libpgo.so (loader, classifier, injector, writers, synthetic generator, shard
+plan) and the C-ABI surface.  No compute call is made here (no GPU in this container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import DATA, DATASETS, ROOT
+
+
+@pytest.mark.parametrize("name", DATASETS)
+def test_loader_matches_python_restatement(pgo, oracle, name):
+    """pgo_g2o_load vs the independent Python restatement of include/g2o_util.h:23-89"""
+    path = os.path.join(DATA, name + ".g2o")
+    g, o = pgo.ReadG2O(path), oracle.read_g2o(path)
+    assert (g.n_poses, g.n_edges) == (o.n_poses, o.n_edges)
+    for mine, theirs in (("pose_ids", "pose_id"), ("poses", "poses"), ("ia", "ia"), ("ib", "ib"), ("meas", "meas"),
+                         ("info", "info"), ("kind", "kind")):
+        np.testing.assert_array_equal(getattr(g, mine), getattr(o, theirs))
+    assert g.n_edges_of_kind(0) + g.n_edges_of_kind(1) == g.n_edges and g.n_edges_of_kind(2) == 0
+    # classifier: odometry iff abs(a-b) < 5, odometry block first (main.cpp:95-130)
+    k = np.array(g.kind)
+    assert np.all((np.abs(np.array(g.ia) - np.array(g.ib)) < 5) == (k == 0))
+    assert np.all(np.diff(k.astype(int)) >= 0)
+
+
+def test_dataset_counts_from_reference_docs(pgo):
+    """DCS-ceres/docs/INTEL/info.txt:2-4 and docs/CSAIL/info.txt:2-4"""
+    g = pgo.ReadG2O(os.path.join(DATA, "INTEL.g2o"))
+    assert (g.n_poses, g.n_edges_of_kind(0), g.n_edges_of_kind(1)) == (1228, 1227, 256)
+    g = pgo.ReadG2O(os.path.join(DATA, "CSAIL.g2o"))
+    assert (g.n_poses, g.n_edges_of_kind(0), g.n_edges_of_kind(1)) == (1045, 1044, 128)
+    g = pgo.ReadG2O(os.path.join(DATA, "MIT.g2o"))  # 20 closure edges written with a > b
+    assert int(np.sum(np.array(g.ia) > np.array(g.ib))) == 20
+
+
+def test_parse_edge_cases(pgo):
+    txt = ("VERTEX_SE2 0 0 0 0\nVERTEX2 1 1.5 0 0.1\nVERTEX_SE2 2 2 0 0\nVERTEX_SE2 3 3 0 0\nVERTEX_SE2 4 4 0 0\n"
+           "VERTEX_SE2 5 5 0 0\nFIX 0\n\n"
+           "EDGE_SE2 0 1  1 0 0.1   1 0 0 1 0 1\n"          # double spaces are compressed
+           "EDGE2 5 0 -5 0 0 1 0 0 1 0 1\n"                 # |a-b| = 5 -> closure
+           "EDGE_SE2 4 0 -4 0 0 1 0 0 1 0 1\r\n"            # |a-b| = 4 -> odometry; CRLF tolerated
+           " EDGE_SE2 1 2 1 0 0 1 0 0 1 0 1\n")             # leading space: boost::split yields an empty first token
+    g = pgo.Graph.parse(txt)
+    assert g.n_poses == 6 and g.n_edges == 3
+    assert list(g.kind) == [0, 0, 1] and list(g.ia) == [0, 4, 5] and list(g.ib) == [1, 0, 0]
+    np.testing.assert_array_equal(g.meas[0], [1, 0, 0.1])
+    g0 = pgo.Graph.parse("")
+    assert g0.n_poses == 0 and g0.n_edges == 0
+    with pytest.raises(pgo.PgoError) as e:
+        pgo.Graph.parse("VERTEX_SE2 0 0 0 0\nEDGE_SE2 0 7 1 0 0 1 0 0 1 0 1\n")
+    assert e.value.status == -3
+    with pytest.raises(pgo.PgoError):
+        pgo.Graph.parse("VERTEX_SE2 0 0 zero 0\n")
+    with pytest.raises(pgo.PgoError):
+        pgo.Graph.parse("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 1 0 0 0\nEDGE_SE2 0 1 1 0\n")  # short record
+    with pytest.raises(pgo.PgoError) as e:
+        pgo.ReadG2O("/nonexistent/file.g2o")
+    assert e.value.status == -2
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 12345])
+def test_injector_matches_glibc_restatement(pgo, oracle, seed):
+    path = os.path.join(DATA, "INTEL.g2o")
+    g = pgo.ReadG2O(path)
+    g.add_random_C(50, seed)
+    o = oracle.add_random_C(oracle.read_g2o(path), 50, seed)
+    for f in ("ia", "ib", "meas", "info", "kind"):
+        np.testing.assert_array_equal(getattr(g, f), getattr(o, f))
+    assert g.n_edges_of_kind(2) == 50
+    assert np.all(np.array(g.kind)[-50:] == 2) and np.all(np.array(g.meas)[-50:] == 0)
+    np.testing.assert_array_equal(np.array(g.info)[-1], [2, 0, 0, 300, 0, 300])
+    # second injection appends after the existing bogus block, odometry|closure|bogus order kept
+    g.add_random_C(3, seed)
+    assert g.n_edges_of_kind(2) == 53 and np.all(np.diff(np.array(g.kind).astype(int)) >= 0)
+
+
+def test_injector_never_creates_self_loops(pgo):
+    g = pgo.Graph.parse("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 1 1 0 0\n")
+    g.add_random_C(200, 7)
+    assert np.all(np.array(g.ia) != np.array(g.ib))
+
+
+def test_writers_format(pgo, tmp_path):
+    """g2o_util.h:93-112,179-186: '<index> <x> <y> <theta>' with default ostream precision; '<a> <b> <type>'"""
+    g = pgo.Graph.parse("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 1 12.3456789 -0.000012345678 3.14159265\n"
+                        "EDGE_SE2 0 1 1 0 0 1 0 0 1 0 1\n")
+    g.add_random_C(1, 3)
+    pn, pe = str(tmp_path / "n.txt"), str(tmp_path / "e.txt")
+    g.writePoseGraph_nodes(pn)
+    g.writePoseGraph_edges(pe)
+    assert open(pn).read().splitlines() == ["0 0 0 0", "1 12.3457 -1.23457e-05 3.14159"]
+    lines = open(pe).read().splitlines()
+    assert lines[0] == "0 1 0" and lines[1].split()[2] == "2"
+    g.writePoseGraph_nodes(pn, 17)
+    back = np.loadtxt(pn)
+    np.testing.assert_array_equal(back[:, 1:], g.poses)
+    # the reference plotter reads columns 1,2 (drawer/plot_results.py)
+    assert np.loadtxt(pn, usecols=(1, 2)).shape == (2, 2)
+    with pytest.raises(pgo.PgoError) as e:
+        g.writePoseGraph_nodes("/nonexistent_dir/x.txt")
+    assert e.value.status == -2
+
+
+def test_g2o_roundtrip(pgo, tmp_path):
+    g = pgo.synth_manhattan(2000, 4.0, 0.10, 11)
+    p = str(tmp_path / "s.g2o")
+    g.write_g2o(p)
+    h = pgo.ReadG2O(p)
+    assert h.n_poses == g.n_poses and h.n_edges == g.n_edges
+    np.testing.assert_array_equal(h.poses, g.poses)
+    # the loader re-classifies by abs(a-b) < 5, so compare as multisets of (a, b, meas)
+    def key(x):
+        arr = np.column_stack([x.ia, x.ib, x.meas])
+        return arr[np.lexsort(arr.T[::-1])]
+    np.testing.assert_array_equal(key(h), key(g))
+
+
+def test_synth_manhattan_properties(pgo):
+    g = pgo.synth_manhattan(20000, 4.0, 0.10, 20260410)
+    g2 = pgo.synth_manhattan(20000, 4.0, 0.10, 20260410)
+    for f in ("poses", "ia", "ib", "meas", "kind"):
+        np.testing.assert_array_equal(getattr(g, f), getattr(g2, f))  # deterministic
+    g3 = pgo.synth_manhattan(20000, 4.0, 0.10, 1)
+    assert not np.array_equal(g3.meas, g.meas)
+    N = g.n_poses
+    no, nc, nb = (g.n_edges_of_kind(k) for k in range(3))
+    assert no == N - 1 and nb == round(0.10 * nc)
+    assert 3.5 * N < g.n_edges < 4.2 * N
+    ia, ib, kind, meas = (np.array(x) for x in (g.ia, g.ib, g.kind, g.meas))
+    assert np.all(ib[kind == 0] - ia[kind == 0] == 1)
+    assert np.all(ib[kind == 1] - ia[kind == 1] >= 5)
+    assert np.all(meas[kind == 2] == 0) and np.all(ia != ib)
+    # odometry: unit steps, noise 0.02 m / 0.01 rad; turns are multiples of 90 degrees
+    od = meas[kind == 0]
+    assert abs(np.mean(od[:, 0]) - 1.0) < 0.01 and 0.015 < np.std(od[:, 0] - 1.0) < 0.025
+    q = od[:, 2] / (np.pi / 2)
+    assert np.max(np.abs(q - np.round(q))) < 0.06
+    # closures link poses that are within 1.5 m of each other in the noise-free world
+    cl = meas[kind == 1]
+    assert np.max(np.hypot(cl[:, 0], cl[:, 1])) < 1.5 + 0.15
+    # initial guess = dead-reckoned odometry
+    p = np.array(g.poses)
+    c, s = np.cos(p[:-1, 2]), np.sin(p[:-1, 2])
+    pred = np.column_stack([p[:-1, 0] + c * od[:, 0] - s * od[:, 1], p[:-1, 1] + s * od[:, 0] + c * od[:, 1],
+                            p[:-1, 2] + od[:, 2]])
+    np.testing.assert_allclose(pred, p[1:], atol=1e-9)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shard_plan(pgo, world):
+    g = pgo.synth_manhattan(10001, 4.0, 0.10, 3)
+    ia, ib = np.array(g.ia), np.array(g.ib)
+    N = g.n_poses
+    rpr = -(-N // world)
+    covered, owned_cost = 0, 0
+    for r in range(world):
+        lo, hi, nl, ncut = pgo.shard_plan(N, ia, ib, world, r)
+        assert (lo, hi) == (min(r * rpr, N), min((r + 1) * rpr, N))
+        oa, ob = (ia >= lo) & (ia < hi), (ib >= lo) & (ib < hi)
+        assert nl == int(np.sum(oa | ob)) and ncut == int(np.sum(oa ^ ob))
+        covered += hi - lo
+        owned_cost += int(np.sum(oa))  # an edge's cost is counted where Edge::a lives
+    assert covered == N and owned_cost == g.n_edges
+    with pytest.raises(pgo.PgoError):
+        pgo.shard_plan(N, ia, ib, 2, 2)
+
+
+# ------------------------------------------------------------------- C-ABI
+def test_library_exports_every_declared_symbol(pgo):
+    hdr = open(os.path.join(ROOT, "include", "pgo.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pgo_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(pgo.EXPORTS), declared ^ set(pgo.EXPORTS)
+    L = ctypes.CDLL(os.path.join(ROOT, "toy-robust-backend-slam_amd", "libpgo.so"))
+    for sym in sorted(declared):
+        assert getattr(L, sym) is not None, sym
+
+
+def test_options_defaults_are_ceres_defaults(pgo):
+    o = pgo.Options()
+    assert (o.method, o.max_iters, o.fixed_pose, o.jacobi_scaling) == (1, 50, 0, 1)
+    assert (o.phi, o.huber_delta) == (0.5, 0.01)
+    assert (o.ftol, o.gtol, o.ptol) == (1e-6, 1e-10, 1e-8)
+    assert (o.radius0, o.max_radius, o.min_radius) == (1e4, 1e16, 1e-32)
+    assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-3, 1e-6, 1e32)
+    assert ctypes.sizeof(pgo.Options) == 4 * 4 + 12 * 8 + 4 * 4 + 8 * 4
+    assert ctypes.sizeof(pgo.IterRecord) == 80 and ctypes.sizeof(pgo.Summary) == 72
+
+
+def test_error_strings(pgo):
+    L = pgo.lib()
+    assert L.pgo_strerror(0) == b"ok" and L.pgo_strerror(-4) == b"no gfx950 device"
+    assert b"unknown" in L.pgo_strerror(-99)
+
+
+def test_solver_fails_loudly_without_gpu(pgo):
+    """no CPU fallback: without a device the product path refuses to run"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    g = pgo.ReadG2O(os.path.join(DATA, "MIT.g2o"))
+    with pytest.raises(pgo.PgoError) as e:
+        pgo.Solver(g)
+    assert e.value.status == -4
+
+
+def test_product_never_touches_the_oracle():
+    """the oracle is test infrastructure: nothing under the package may import, link or load it"""
+    pkg = os.path.join(ROOT, "toy-robust-backend-slam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".c")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pgo_oracle" not in txt and "import oracle" not in txt and "oracle/" not in txt, os.path.join(dirpath, f)

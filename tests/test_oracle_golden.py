@@ -1,0 +1,169 @@
+"""CPU: the oracle (oracle/) against known-answer values.
+
+PARITY UNPINNED with respect to the reference binary: the reference ships no tests and cannot be built
+here.  What pins the oracle instead:
+  * SURVEY.md section 8(c) known-answer values, derived there from the reference's formulas with an
+    independent closed-form numpy restatement (the oracle uses forward-mode Jets through the
+    reference's matrix expression, so the two derivations share no code);
+  * finite differences of the oracle's own residual;
+  * the committed fixtures under tests/golden/ (regression of the restatement).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN, DATASETS
+
+# initial cost 1/2 sum rho at the file poses, METHOD 0 / METHOD 1, and #edges with psi < 1
+KNOWN = {
+    "INTEL": (3.082223216921e+01, 2.471759982854e+00, 251),
+    "MIT": (1.459953365886e+01, 1.959203269806e-01, 20),
+    "CSAIL": (4.063356725792e+00, 9.610536556244e-01, 97),
+    "FR079": (4.870069294740e-01, 4.865471483015e-01, 1),
+    "FRH": (2.254308375633e-03, 2.254308375633e-03, 0),
+    "M3500": (4.989870673947e+01, 1.163382523718e+01, 992),
+}
+
+
+@pytest.mark.parametrize("name", DATASETS)
+def test_initial_costs_known_answers(oracle, name):
+    g = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
+    c0 = oracle.evaluate(g, method=0, want_r=False, want_J=False)[0]
+    c1 = oracle.evaluate(g, method=1, want_r=False, want_J=False)[0]
+    e0, e1, npsi = KNOWN[name]
+    assert c0 == pytest.approx(e0, rel=1e-11)
+    assert c1 == pytest.approx(e1, rel=1e-11)
+    _, r0, _ = oracle.evaluate(g, method=0, apply_loss=False, want_J=False)
+    _, r1, _ = oracle.evaluate(g, method=1, apply_loss=False, want_J=False)
+    assert int(np.sum(np.abs(r1 - r0).max(axis=1) > 0)) == npsi
+    fx = json.load(open(os.path.join(GOLDEN, "initial_costs.json")))[name]
+    assert fx["cost_method0"] == pytest.approx(c0, rel=1e-13) and fx["cost_method1"] == pytest.approx(c1, rel=1e-13)
+    assert fx["n_poses"] == g.n_poses and fx["n_edges"] == g.n_edges
+
+
+def test_intel_first_closure_edge(oracle):
+    """file edge #1227 (19 -> 166)"""
+    g = oracle.read_g2o(os.path.join(DATA, "INTEL.g2o"))
+    k = 1227
+    assert (g.ia[k], g.ib[k]) == (19, 166) and g.kind[k] == 1
+    np.testing.assert_allclose(g.meas[k], [-2.459689, 0.241111, 0.2528])
+    e, J = oracle.edge(g.poses[19], g.poses[166], g.meas[k], False)
+    np.testing.assert_allclose(e, [0.3442233556645796, -2.1712824454602253, 0.01997599999999999], rtol=1e-12)
+    e, J = oracle.edge(g.poses[19], g.poses[166], g.meas[k], True)
+    np.testing.assert_allclose(e, [0.14905834188090758, -0.9402260356522534, 0.00865016678390194], rtol=1e-12)
+    np.testing.assert_allclose(J[0], [-0.42651265331100036, -0.032300575930653677, -0.44002998504004065,
+                                      0.42651265331100036, 0.032300575930653677, 0.0], rtol=1e-11, atol=1e-15)
+    e, J = oracle.edge(g.poses[3], g.poses[4], g.meas[3], False)
+    np.testing.assert_allclose(J[:, 2], [-0.00553499534995826, -0.630064658973566, -1.0], rtol=1e-11)
+
+
+def test_asin_fold(oracle):
+    """theta error is asin(sin d): folds to [-pi/2, pi/2] with derivative sign(cos d)"""
+    e, J = oracle.edge([0, 0, 0], [0, 0, 2.5], [0, 0, 0], False)
+    assert e[2] == pytest.approx(np.pi - 2.5, rel=1e-13)
+    assert J[2, 5] == pytest.approx(-1.0, rel=1e-12) and J[2, 2] == pytest.approx(1.0, rel=1e-12)
+    e, J = oracle.edge([0, 0, 0], [0, 0, 1.0], [0, 0, 0], False)
+    assert J[2, 5] == pytest.approx(1.0, rel=1e-12)
+
+
+@pytest.mark.parametrize("dcs", [False, True])
+def test_jet_jacobian_matches_finite_differences(oracle, dcs):
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        P1, P2 = rng.uniform(-3, 3, 3), rng.uniform(-3, 3, 3)
+        m = rng.uniform(-2, 2, 3)
+        e, J = oracle.edge(P1, P2, m, dcs)
+        x = np.concatenate([P1, P2])
+        num = np.zeros((3, 6))
+        h = 1e-6
+        for k in range(6):
+            xp, xm = x.copy(), x.copy()
+            xp[k] += h
+            xm[k] -= h
+            num[:, k] = (oracle.edge(xp[:3], xp[3:], m, dcs, jac=False) - oracle.edge(xm[:3], xm[3:], m, dcs, jac=False)) / (2 * h)
+        ed = oracle.edge(P1, P2, m, dcs, jac=False)
+        np.testing.assert_allclose(ed, e, rtol=1e-13, atol=1e-15)   # T=double and T=Jet instantiations agree
+        if abs(abs(np.sin(P2[2] - P1[2] - m[2])) - 1) < 1e-3:
+            continue
+        np.testing.assert_allclose(J, num, rtol=2e-6, atol=2e-7)
+
+
+def test_dcs_is_identity_inside_phi(oracle):
+    """psi == 1 with zero derivative when ex^2 + ey^2 <= phi (Jet min picks T(1.0))"""
+    P1, P2, m = [0.1, 0.2, 0.3], [0.5, 0.1, 0.4], [0.3, -0.1, 0.1]
+    e0, J0 = oracle.edge(P1, P2, m, False)
+    e1, J1 = oracle.edge(P1, P2, m, True)
+    assert e0[0] ** 2 + e0[1] ** 2 < 0.5
+    np.testing.assert_array_equal(e0, e1)
+    np.testing.assert_array_equal(J0, J1)
+
+
+def test_huber(oracle):
+    a = 0.01
+    np.testing.assert_allclose(oracle.huber(0.5e-4, a), [0.5e-4, 1.0, 0.0])
+    s = 4.0
+    rho = oracle.huber(s, a)
+    np.testing.assert_allclose(rho, [2 * a * 2.0 - a * a, a / 2.0, -(a / 2.0) / (2 * s)])
+
+
+def test_glibc_rand_restatement(oracle):
+    r = oracle.GlibcRand(1)
+    assert [r.rand() for _ in range(5)] == [1804289383, 846930886, 1681692777, 1714636915, 1957747793]
+
+
+def test_injector_known_answers(oracle):
+    g = oracle.read_g2o(os.path.join(DATA, "INTEL.g2o"))
+    g2 = oracle.add_random_C(g, 50, 1)
+    assert list(zip(g2.ia[-50:][:4].tolist(), g2.ib[-50:][:4].tolist())) == [(35, 162), (1175, 1086), (422, 711), (46, 660)]
+    assert np.all(g2.meas[-50:] == 0.0) and np.all(g2.kind[-50:] == 2)
+    c = oracle.evaluate(g2, method=1, want_r=False, want_J=False)[0]
+    assert c == pytest.approx(2.969102e+00, rel=1e-6)
+    fx = json.load(open(os.path.join(GOLDEN, "intel_bogus.json")))
+    for seed in (1, 2, 3):
+        gg = oracle.add_random_C(g, 50, seed)
+        assert gg.ia[-50:].tolist() == fx[str(seed)]["a"] and gg.ib[-50:].tolist() == fx[str(seed)]["b"]
+
+
+def test_edge_fixture_regression(oracle):
+    for rec in json.load(open(os.path.join(GOLDEN, "intel_edges.json"))):
+        for dcs in (0, 1):
+            e, J = oracle.edge(rec["P1"], rec["P2"], rec["meas"], bool(dcs))
+            np.testing.assert_allclose(e, rec["e%d" % dcs], rtol=1e-13, atol=1e-16)
+            np.testing.assert_allclose(J.reshape(-1), rec["J%d" % dcs], rtol=1e-13, atol=1e-16)
+
+
+def test_lm_direct_intel_matches_fixture_and_baseline_md(oracle):
+    """INTEL METHOD 1, 50 srand(1) outliers: 2.9691 -> 0.66796 at the 50-iteration cap"""
+    g = oracle.add_random_C(oracle.read_g2o(os.path.join(DATA, "INTEL.g2o")), 50, 1)
+    res = oracle.lm_direct(g, oracle.Options(method=1))
+    assert res.termination == 4 and res.iterations == 50
+    assert res.initial_cost == pytest.approx(2.9691, rel=1e-4) and res.final_cost == pytest.approx(0.66796, rel=1e-4)
+    fx = json.load(open(os.path.join(GOLDEN, "lm_INTEL_out50_m1.json")))
+    assert res.final_cost == pytest.approx(fx["final_cost"], rel=1e-9)
+    ref = np.load(os.path.join(GOLDEN, "lm_INTEL_out50_m1_poses.npy"))
+    assert np.abs(res.poses - ref).max() < 1e-7
+    for a, b in zip(res.records, fx["records"]):
+        assert a["step_ok"] == b["step_ok"] and a["radius"] == pytest.approx(b["radius"], rel=1e-9)
+
+
+def test_lm_pcg_port_tracks_direct_solve(oracle):
+    """the C "port" (block-Jacobi PCG) follows the direct-solve trajectory when solved tightly"""
+    g = oracle.read_g2o(os.path.join(DATA, "INTEL.g2o"))
+    a = oracle.lm_direct(g, oracle.Options(method=1, max_iters=6))
+    b = oracle.lm_pcg(g, oracle.Options(method=1, max_iters=6, pcg_rtol=1e-12, pcg_max_iters=100000, threads=4))
+    assert a.iterations == b.iterations == 6
+    assert np.abs(a.poses - b.poses).max() < 1e-8
+    assert a.final_cost == pytest.approx(b.final_cost, rel=1e-9)
+
+
+def test_lm_policy_rejected_step_shrinks_radius(oracle):
+    """a huge initial radius on a hard start forces rejected steps: radius /= 2, 4, ... (LevenbergMarquardtStrategy)"""
+    g = oracle.read_g2o(os.path.join(DATA, "M3500.g2o"))
+    res = oracle.lm_direct(g, oracle.Options(method=0, max_iters=12, radius0=1e12, huber_delta=0.0))
+    rej = [r for r in res.records if r["step_ok"] == 0]
+    costs = [r["cost"] for r in res.records if r["step_ok"] == 1]
+    assert all(x >= y for x, y in zip(costs, costs[1:]))  # monotone
+    for r in rej:
+        assert r["relative_decrease"] <= 1e-3
