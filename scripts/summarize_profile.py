@@ -1,0 +1,110 @@
+"""Condense rocprofv3 CSV output (scripts/profile.sh) into small files under profiles/.
+
+Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3's --stats table), profiles/<tag>_summary.md and
+profiles/pmc_traffic.json (HBM bytes per launch of the hot kernels from FETCH_SIZE / WRITE_SIZE).
+
+Counter handling follows MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are collected in
+separate passes; both are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by
+2x and other access widths are uncalibrated, so the read side is CALIBRATED here on kernels of this
+code base with a known byte count and the same 8-byte-per-lane access pattern (k_dot reads exactly
+2 x 8 x n bytes; k_scatter_owned reads and writes 8 x n), and the factors are reported.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def read_csv(pattern):
+    rows = []
+    for f in glob.glob(pattern, recursive=True):
+        with open(f, newline="") as fh:
+            rows += list(csv.DictReader(fh))
+    return rows
+
+
+def short(name):
+    n = name
+    for k in ("k_edge_eval<true>", "k_edge_eval<false>", "k_edge_evalILb1", "k_edge_evalILb0", "k_assemble", "k_spmv",
+              "k_cg_update1", "k_cg_update2", "k_cg_init_fin", "k_cg_init", "k_prepare", "k_finalize", "k_dot",
+              "k_candidate", "k_scatter_owned", "k_grad_max", "k_xnorm", "k_jacobi_scale", "k_flag_to_double", "k_fill"):
+        if k in n:
+            return {"k_edge_evalILb1": "k_edge_eval<true>", "k_edge_evalILb0": "k_edge_eval<false>"}.get(k, k)
+    return n[:60]
+
+
+def main():
+    out_dir, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    stats = read_csv(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"))
+    lines = ["# rocprofv3 --kernel-trace --stats, bench.py --steps 3 --warmup 1 (1M poses, 1 GPU)", "",
+             "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+    with open(os.path.join(prof, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+        if stats:
+            w = csv.DictWriter(fh, fieldnames=list(stats[0].keys()))
+            w.writeheader()
+            w.writerows(stats)
+    for r in stats:
+        name = short(r.get("Name", ""))
+        calls = int(r.get("Calls", 0))
+        tot = float(r.get("TotalDurationNs", 0)) / 1e6
+        avg = float(r.get("AverageNs", 0)) / 1e3
+        lines.append(f"| {name} | {calls} | {tot:.3f} | {avg:.2f} | {r.get('Percentage', '')} |")
+
+    # counters: one row per dispatch and counter
+    def per_kernel(pass_dir, counter):
+        acc = defaultdict(list)
+        for r in read_csv(os.path.join(out_dir, pass_dir, "**", "*counter_collection.csv")):
+            if r.get("Counter_Name") != counter:
+                continue
+            acc[short(r.get("Kernel_Name", ""))].append(float(r.get("Counter_Value", 0)))
+        return acc
+
+    fetch = per_kernel("pmc_fetch", "FETCH_SIZE")
+    write = per_kernel("pmc_write", "WRITE_SIZE")
+    pmc = {"units": "bytes per launch; FETCH_SIZE/WRITE_SIZE are KiB; read side multiplied by the calibration factor",
+           "n_poses": 1000000}
+    lines += ["", "## PMC (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes)", "",
+              "| kernel | launches | FETCH_SIZE KiB avg | WRITE_SIZE KiB avg |", "|---|---|---|---|"]
+    for k in sorted(set(fetch) | set(write)):
+        f = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else float("nan")
+        w_ = sum(write[k]) / len(write[k]) if write.get(k) else float("nan")
+        lines.append(f"| {k} | {len(fetch.get(k, []))} | {f:.1f} | {w_:.1f} |")
+        pmc[k] = {"fetch_kib": f, "write_kib": w_}
+    json.dump(pmc, open(os.path.join(prof, f"{tag}_pmc_raw.json"), "w"), indent=1)
+    # calibration on known byte counts (n = 3N doubles): k_dot reads 2*8n, k_xnorm reads 2*8n,
+    # k_scatter_owned reads 8n and writes 8n
+    n_bytes = 8.0 * 3 * pmc["n_poses"]
+    cal = {}
+    if "k_dot" in pmc and pmc["k_dot"]["fetch_kib"] > 0:
+        cal["read_factor_k_dot"] = 2 * n_bytes / (pmc["k_dot"]["fetch_kib"] * 1024)
+    if "k_xnorm" in pmc and pmc["k_xnorm"]["fetch_kib"] > 0:
+        cal["read_factor_k_xnorm"] = 2 * n_bytes / (pmc["k_xnorm"]["fetch_kib"] * 1024)
+    if "k_scatter_owned" in pmc:
+        cal["read_factor_k_scatter"] = n_bytes / (pmc["k_scatter_owned"]["fetch_kib"] * 1024)
+        cal["write_factor_k_scatter"] = n_bytes / (pmc["k_scatter_owned"]["write_kib"] * 1024)
+    rf = cal.get("read_factor_k_dot", 2.0)
+    wf = cal.get("write_factor_k_scatter", 1.0)
+    traffic = {"calibration": cal, "read_factor_used": rf, "write_factor_used": wf,
+               "note": "bytes per launch = FETCH_SIZE*1024*read_factor + WRITE_SIZE*1024*write_factor (gfx950: FETCH_SIZE "
+                       "counts half the bytes of coalesced streaming reads, MI355X_MICROARCH.md section HBM; factors "
+                       "calibrated on k_dot / k_scatter_owned, whose byte counts are known)"}
+    lines += ["", "## HBM traffic per launch (calibrated)", "", f"read factor {rf:.3f}, write factor {wf:.3f} ({cal})", "",
+              "| kernel | read MB | write MB | total MB |", "|---|---|---|---|"]
+    for k, v in pmc.items():
+        if not isinstance(v, dict) or not k.startswith("k_"):
+            continue
+        rd, wr = v["fetch_kib"] * 1024 * rf, v["write_kib"] * 1024 * wf
+        traffic[k.replace("<true>", "_jac").replace("<false>", "_cost") + "_bytes_per_launch"] = rd + wr
+        lines.append(f"| {k} | {rd / 1e6:.1f} | {wr / 1e6:.1f} | {(rd + wr) / 1e6:.1f} |")
+    json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
+    open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
