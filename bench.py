@@ -61,9 +61,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     comm = None
-    if world > 1:
+    force_dist = os.environ.get("PGO_BENCH_FORCE_DIST") == "1"  # exercise the distributed path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(P.Comm.unique_id()), dtype=torch.uint8))

@@ -15,6 +15,7 @@
 #include <functional>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -100,6 +101,11 @@ struct pgo_handle {
     if (stream) (void)hipStreamDestroy(stream);
   }
 
+  // collectives are skipped for a single rank unless PGO_FORCE_COLLECTIVES=1 (lets a 1-GPU box
+  // exercise the RCCL calls themselves: at world == 1 they are identities)
+  bool force_collectives = false;
+  bool multi_rank() const { return comm && (comm->world > 1 || force_collectives); }
+
   template <class T>
   int dalloc(T** out, int64_t n) {
     void* p = nullptr;
@@ -143,7 +149,7 @@ struct pgo_handle {
     F.out = scal + first;
     hipLaunchKernelGGL(dev::k_finalize, dim3(1), dim3(dev::WG), 0, stream, F);
     PGOC(check_launch("k_finalize"));
-    if (comm && comm->world > 1) PGOC(comm->allreduce(scal + first, k, allreduce_max, stream));
+    if (multi_rank()) PGOC(comm->allreduce(scal + first, k, allreduce_max, stream));
     return PGO_OK;
   }
   int fetch_scal(int first, int count) {
@@ -151,7 +157,7 @@ struct pgo_handle {
     return sync();
   }
   int allgather(double* full) {
-    if (comm && comm->world > 1) PGOC(comm->allgather_inplace(full, (int64_t)3 * S.rows_per_rank, stream));
+    if (multi_rank()) PGOC(comm->allgather_inplace(full, (int64_t)3 * S.rows_per_rank, stream));
     return PGO_OK;
   }
 
@@ -260,6 +266,8 @@ struct pgo_handle {
 int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_t* ia, const int32_t* ib,
                        const double* meas, const uint8_t* kind) {
   const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+  const char* fc = getenv("PGO_FORCE_COLLECTIVES");
+  force_collectives = fc && fc[0] == '1';
   PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, &S));
   HIPC(hipSetDevice(device));
   HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -396,7 +404,7 @@ int pgo_handle::lm_begin() {
 // pcg_check_every iterations; in between the kernels early-out on st->done.
 int pgo_handle::pcg(int* iters, double* rel) {
   dev::CgVec V = cg_vec();
-  const bool multi = comm && comm->world > 1;
+  const bool multi = multi_rank();
   hipLaunchKernelGGL(dev::k_cg_init, dim3(g_vec), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
   PGOC(check_launch("k_cg_init"));
   PGOC(reduce_to_scal({{part[0], g_vec, 0}, {part[1], g_vec, 0}}, 4));
@@ -459,7 +467,7 @@ int pgo_handle::lm_iteration(bool* stop) {
   pgo_iter_record R;
   memset(&R, 0, sizeof R);
   R.iter = iter;
-  const bool multi = comm && comm->world > 1;
+  const bool multi = multi_rank();
 
   // LM diagonal + preconditioner, then the linear solve
   double t0 = wall_s();
