@@ -1,0 +1,151 @@
+// The slice of the ceres API that DCS-ceres/main.cpp:66-164 uses, re-hosted on libpgo.so:
+//   Problem::AddResidualBlock(cost, loss, p1, p2)   main.cpp:99,114,128,137,148
+//   Problem::SetParameterBlockConstant(p)           main.cpp:153
+//   Solver::Options / Solver::Summary / Solve()     main.cpp:154-164
+// Parameter blocks are identified by their double* (Node::p), as in Ceres, and are updated in place.
+#ifndef PGO_HOST_PROBLEM_H_
+#define PGO_HOST_PROBLEM_H_
+
+#include <cstdio>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "ceres_error.h"
+#include "pgo.h"
+
+namespace pgo {
+
+struct LossFunction {
+  virtual ~LossFunction() {}
+  virtual double huber_delta() const = 0;
+};
+struct HuberLoss : LossFunction {  // ceres::HuberLoss(a), main.cpp:68
+  explicit HuberLoss(double a) : a_(a) {}
+  double huber_delta() const override { return a_; }
+  double a_;
+};
+
+enum LinearSolverType { SPARSE_NORMAL_CHOLESKY, BLOCK_JACOBI_PCG };
+
+class Problem {
+ public:
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* p1, double* p2) {
+    std::unique_ptr<CostFunction> own(cost);  // TAKE_OWNERSHIP, as Ceres does by default
+    if (p1 == p2) throw std::invalid_argument("duplicate parameter block in a residual block");
+    ia_.push_back(block(p1));
+    ib_.push_back(block(p2));
+    meas_.insert(meas_.end(), {cost->dx, cost->dy, cost->dtheta});
+    kind_.push_back(cost->dcs ? PGO_EDGE_CLOSURE : PGO_EDGE_ODOMETRY);
+    any_dcs_ = any_dcs_ || cost->dcs;
+    const double d = loss ? loss->huber_delta() : 0.0;
+    if (!ia_.empty() && ia_.size() > 1 && d != delta_) mixed_loss_ = true;
+    delta_ = d;
+  }
+  void SetParameterBlockConstant(double* p) { fixed_ = block(p); }
+  int NumResidualBlocks() const { return (int)ia_.size(); }
+  int NumParameterBlocks() const { return (int)ptr_.size(); }
+
+ private:
+  friend struct SolverAccess;
+  int32_t block(double* p) {
+    auto it = id_.find(p);
+    if (it != id_.end()) return it->second;
+    int32_t k = (int32_t)ptr_.size();
+    id_[p] = k;
+    ptr_.push_back(p);
+    return k;
+  }
+  std::unordered_map<double*, int32_t> id_;
+  std::vector<double*> ptr_;
+  std::vector<int32_t> ia_, ib_;
+  std::vector<double> meas_;
+  std::vector<uint8_t> kind_;
+  int32_t fixed_ = -1;
+  double delta_ = 0.0;
+  bool any_dcs_ = false, mixed_loss_ = false;
+};
+
+namespace Solver {
+struct Options {
+  bool minimizer_progress_to_stdout = false;
+  LinearSolverType linear_solver_type = SPARSE_NORMAL_CHOLESKY;  // accepted; solved by block-Jacobi PCG to pcg_rtol
+  int max_num_iterations = 50;
+  double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  double initial_trust_region_radius = 1e4;
+  double pcg_rtol = 1e-10;
+  int pcg_max_iters = 200000;
+  int device = 0;
+};
+struct Summary {
+  pgo_summary s{};
+  std::vector<pgo_iter_record> iterations;
+  int num_parameter_blocks = 0, num_residual_blocks = 0;
+  std::string FullReport() const {
+    static const char* term[] = {"?", "CONVERGENCE (function tolerance)", "CONVERGENCE (gradient tolerance)",
+                                 "CONVERGENCE (parameter tolerance)", "NO_CONVERGENCE (max iterations)",
+                                 "NO_CONVERGENCE (min trust region radius)", "FAILURE"};
+    std::ostringstream o;
+    char b[256];
+    o << "\nSolver Summary (pgo-amd, MI355X HIP backend)\n\n";
+    o << "Parameter blocks   " << num_parameter_blocks << "\nResidual blocks    " << num_residual_blocks << "\n";
+    o << "Linear solver      block-Jacobi PCG (total " << s.total_pcg_iters << " iterations)\n\n";
+    snprintf(b, sizeof b, "Cost:\nInitial  %.6e\nFinal    %.6e\nChange   %.6e\n\n", s.initial_cost, s.final_cost, s.initial_cost - s.final_cost);
+    o << b;
+    o << "Minimizer iterations  " << s.iterations << "\nSuccessful steps      " << s.successful_steps << "\n\n";
+    snprintf(b, sizeof b, "Time (in seconds):\n  Residual+Jacobian  %.6f\n  Assembly           %.6f\n  Linear solver      %.6f\n  Candidate cost     %.6f\nTotal                %.6f\n\n",
+             s.seconds_eval, s.seconds_assemble, s.seconds_linear, s.seconds_candidate, s.seconds_total);
+    o << b << "Termination: " << term[(s.termination >= 0 && s.termination <= 6) ? s.termination : 0] << "\n";
+    return o.str();
+  }
+};
+}  // namespace Solver
+
+struct SolverAccess {
+  static void Solve(const Solver::Options& opt, Problem* pr, Solver::Summary* sum) {
+    if (pr->mixed_loss_) throw std::invalid_argument("this backend needs one shared loss for all residual blocks (as main.cpp:68)");
+    const int32_t N = (int32_t)pr->ptr_.size(), E = (int32_t)pr->ia_.size();
+    std::vector<double> poses((size_t)3 * N);
+    for (int32_t i = 0; i < N; ++i)
+      for (int k = 0; k < 3; ++k) poses[3 * (size_t)i + k] = pr->ptr_[i][k];
+    pgo_options o;
+    pgo_options_default(&o);
+    o.method = pr->any_dcs_ ? 1 : 0;
+    o.huber_delta = pr->delta_;
+    o.fixed_pose = pr->fixed_;
+    o.max_iters = opt.max_num_iterations;
+    o.ftol = opt.function_tolerance;
+    o.gtol = opt.gradient_tolerance;
+    o.ptol = opt.parameter_tolerance;
+    o.radius0 = opt.initial_trust_region_radius;
+    o.pcg_rtol = opt.pcg_rtol;
+    o.pcg_max_iters = opt.pcg_max_iters;
+    o.verbose = opt.minimizer_progress_to_stdout ? 1 : 0;
+    pgo_t* h = nullptr;
+    auto check = [](int st) {
+      if (st != PGO_OK) throw std::runtime_error(std::string("pgo: ") + pgo_strerror(st) + ": " + pgo_last_error());
+    };
+    check(pgo_create(&h, N, poses.data(), E, pr->ia_.data(), pr->ib_.data(), pr->meas_.data(), pr->kind_.data(), &o, nullptr, opt.device));
+    int st = pgo_solve(h, &sum->s);
+    if (st == PGO_OK) st = pgo_get_poses(h, poses.data());
+    if (st == PGO_OK) {
+      sum->iterations.resize((size_t)pgo_num_iter_records(h));
+      st = pgo_get_iter_records(h, sum->iterations.data(), (int32_t)sum->iterations.size());
+    }
+    pgo_destroy(h);
+    check(st);
+    for (int32_t i = 0; i < N; ++i)  // in place, like Ceres
+      for (int k = 0; k < 3; ++k) pr->ptr_[i][k] = poses[3 * (size_t)i + k];
+    sum->num_parameter_blocks = N;
+    sum->num_residual_blocks = E;
+  }
+};
+
+inline void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summary) { SolverAccess::Solve(opt, problem, summary); }
+
+}  // namespace pgo
+
+#endif
