@@ -189,6 +189,11 @@ def _bp(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint8))
 
 
+class _View(np.ndarray):
+    """ndarray view into memory owned by a Graph; keeps the Graph alive while the view (or a slice) lives"""
+    _owner = None
+
+
 class Graph:
     """Host-side pose graph (owns a pgo_graph*).  Arrays are exposed as numpy views."""
 
@@ -248,7 +253,9 @@ class Graph:
         if n == 0:
             return np.zeros(shape, dtype)
         ptr = fn(self._h)
-        return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape)
+        v = np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape).view(_View)
+        v._owner = self
+        return v
 
     @property
     def pose_ids(self):

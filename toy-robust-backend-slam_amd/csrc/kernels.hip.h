@@ -19,6 +19,27 @@ namespace dev {
 constexpr int WG = 256;          // workgroup size of every kernel here (4 waves)
 constexpr int REC = 22;          // doubles per edge record: J (18, row-major 3x6) | r (3) | cost (1)
 constexpr int REC_LDS = 23;      // odd stride => conflict-free ds_write_b64 when staging records
+constexpr int PS = 3;            // doubles per pose in the GATHERED vector p.  Padding to 4 (32 B, never straddling a
+                                 // 64-byte sector) was measured: no fewer fetched bytes (FETCH_SIZE 566 vs 557 MiB), so 3.
+
+// ------------------------------------------------- XCD-aware work mapping
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD; speed only, never
+// correctness).  Each XCD has its own 4 MiB L2, so consecutive tiles -- which gather the same pose /
+// search-direction sectors and re-read each other's edge records -- should run on ONE XCD: the item
+// range is cut into 8 contiguous parts and workgroup b walks part (b % 8) with stride gridDim/8.
+// Requires gridDim.x % 8 == 0.
+struct XcdRange {
+  int begin, end, step;
+};
+__device__ __forceinline__ XcdRange xcd_range(int n_items) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int chunk = (n_items + 7) >> 3;
+  XcdRange r;
+  r.begin = min(n_items, xcd * chunk) + slot;
+  r.end = min(n_items, (xcd + 1) * chunk);
+  r.step = per_xcd;
+  return r;
+}
 
 // ------------------------------------------------------------- reductions
 __device__ __forceinline__ double wave_sum(double v) {
@@ -84,8 +105,13 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
   __shared__ double stage[WITH_JAC ? WG * REC_LDS : 1];
   __shared__ double red[8];
   const int tid = threadIdx.x;
-  const int64_t e0 = (int64_t)blockIdx.x * WG;
-  const int64_t e = e0 + tid;
+  // XCD-aware: consecutive 256-edge blocks (sorted by min endpoint => shared pose sectors) share an XCD
+  const int n_blocks = (A.n_edges + WG - 1) / WG;
+  const int per_xcd = (n_blocks + 7) >> 3;
+  const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const bool live = (blockIdx.x >> 3) < per_xcd && blk < n_blocks;
+  const int64_t e0 = (int64_t)blk * WG;
+  const int64_t e = live ? e0 + tid : (int64_t)A.n_edges;
   double cost = 0.0;
   if (e < A.n_edges) {
     const int a = A.ia[e], b = A.ib[e];
@@ -173,7 +199,7 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
     // transpose through LDS so that the 176-byte records leave as 16-byte-per-lane
     // coalesced stores (a lane-per-record store would touch ~90 lines per instruction)
     __syncthreads();
-    int64_t nvalid = A.n_edges - e0;
+    int64_t nvalid = live ? A.n_edges - e0 : 0;
     if (nvalid > WG) nvalid = WG;
     const int ndbl = (int)nvalid * REC;
     double* out = jr + e0 * REC;  // 16-byte aligned: e0 * 176
@@ -212,7 +238,8 @@ struct AsmArgs {
 __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
   __shared__ double scr[9][WG];
   const int tid = threadIdx.x;
-  for (int t = blockIdx.x; t < A.n_tiles; t += gridDim.x) {
+  const XcdRange xr = xcd_range(A.n_tiles);
+  for (int t = xr.begin; t < xr.end; t += xr.step) {
     const int r0 = A.tile_row[t], r1 = A.tile_row[t + 1];
     const int nrows = r1 - r0;
     const int q0 = A.inc_ptr[r0], q1 = A.inc_ptr[r1];
@@ -303,69 +330,124 @@ struct SpmvArgs {
 
 // Algorithmic bytes: 76 per off-diagonal block (72 value + 4 column index) + per row
 // 48 (diagonal planes) + 24 (D'D) + 4 (row pointer) + 24 (y) + 24 (p, counted once).
-__global__ __launch_bounds__(WG) void k_spmv(SpmvArgs A) {
-  __shared__ double scr[3][WG];
+// MODE 0 = the product kernel.  MODE 1..3 are timing-only ablations used by pgo_bench_spmv under
+// PGO_SPMV_ABLATE (1: no p[col] gather, 2: no H-plane loads, 3: neither): wrong results, same structure.
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
+  // double-buffered staging: ONE barrier per tile (the barrier of tile t+1 orders every wave's row
+  // phase of tile t before any wave's lane phase of tile t+2, which reuses the buffer)
+  __shared__ double scr[2][3][WG];
   __shared__ double red[8];
   const int tid = threadIdx.x;
   if (A.done && *A.done) return;
   double dot = 0.0;
-  for (int t = blockIdx.x; t < A.n_tiles; t += gridDim.x) {
+  int buf = 0;
+  const int64_t n = A.n_loc, S = A.inc_stride;
+  const XcdRange xr = xcd_range(A.n_tiles);
+  for (int t = xr.begin; t < xr.end; t += xr.step) {
     const int r0 = A.tile_row[t], r1 = A.tile_row[t + 1];
     const int nrows = r1 - r0;
     const int q0 = A.inc_ptr[r0], q1 = A.inc_ptr[r1];
-    const bool multi = (q1 - q0) > WG;
-    double acc = 0.0;
-    for (int base = q0; base < q1 || base == q0; base += WG) {
-      const int q = base + tid;
+    if (q1 - q0 <= WG) {
+      // ---- common case: the tile is one chunk.  Row-phase operands are fetched up front so that
+      // their latency overlaps the lane phase instead of following the barrier.
+      const bool pv = tid < nrows * 3;
+      int a = 0, row = r0, lo = 0, hi = 0;
+      double h0 = 0.0, h1 = 0.0, h2 = 0.0, dd = 0.0, pr0 = 0.0, pr1 = 0.0, pr2 = 0.0;
+      if (pv) {
+        a = tid / nrows;
+        row = r0 + (tid - a * nrows);
+        lo = A.inc_ptr[row] - q0;
+        hi = A.inc_ptr[row + 1] - q0;
+        const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
+        h0 = A.hd[(int64_t)a * n + row];
+        h1 = A.hd[(int64_t)i1 * n + row];
+        h2 = A.hd[(int64_t)i2 * n + row];
+        if (A.with_d2) dd = A.d2[3 * (int64_t)row + a];
+        const double* pr = A.p + PS * (int64_t)(A.lo + row);
+        pr0 = pr[0];
+        pr1 = pr[1];
+        pr2 = pr[2];
+      }
+      const int q = q0 + tid;
       if (q < q1) {
         const int64_t col = A.inc_col[q];
-        const double p0 = A.p[3 * col], p1 = A.p[3 * col + 1], p2 = A.p[3 * col + 2];
-        const double* h = A.hoff + q;
-        const int64_t S = A.inc_stride;
-        scr[0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
-        scr[1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
-        scr[2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
-      }
-      __syncthreads();
-      for (int idx = tid; idx < nrows * 3; idx += WG) {
-        const int a = idx / nrows, rl = idx - a * nrows;
-        const int row = r0 + rl;
-        int lo = A.inc_ptr[row], hi = A.inc_ptr[row + 1];
-        lo = max(lo, base) - base;
-        hi = min(hi, base + WG) - base;
-        double s = 0.0;
-        for (int j = lo; j < hi; ++j) s += scr[a][j];
-        if (multi) {
-          acc += s;
+        double p0, p1, p2;
+        if (MODE == 1 || MODE == 3) {
+          p0 = (double)col; p1 = p0 + 1.0; p2 = p0 + 2.0;
         } else {
-          // diagonal block row a of the symmetric 3x3 + LM diagonal
-          const double* pr = A.p + 3 * (int64_t)(A.lo + row);
-          const int64_t n = A.n_loc;
-          const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
-          double d = A.hd[(int64_t)a * n + row] * pr[0];
-          d += A.hd[(int64_t)i1 * n + row] * pr[1];
-          d += A.hd[(int64_t)i2 * n + row] * pr[2];
-          if (A.with_d2) d += A.d2[3 * (int64_t)row + a] * pr[a];
-          s += d;
-          A.y[3 * (int64_t)row + a] = s;
-          dot += pr[a] * s;
+          p0 = A.p[PS * col]; p1 = A.p[PS * col + 1]; p2 = A.p[PS * col + 2];
+        }
+        const double* h = A.hoff + q;
+        if (MODE == 2 || MODE == 3) {
+          scr[buf][0][tid] = p0 + 2.0 * p1 + 3.0 * p2;
+          scr[buf][1][tid] = p0 - p1;
+          scr[buf][2][tid] = p2 * p1;
+        } else {
+          scr[buf][0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
+          scr[buf][1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
+          scr[buf][2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
         }
       }
       __syncthreads();
-      if (q1 == q0) break;
-    }
-    if (multi && tid < 3) {  // single heavy row
-      const int a = tid, row = r0;
-      const double* pr = A.p + 3 * (int64_t)(A.lo + row);
-      const int64_t n = A.n_loc;
-      const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
-      double d = A.hd[(int64_t)a * n + row] * pr[0];
-      d += A.hd[(int64_t)i1 * n + row] * pr[1];
-      d += A.hd[(int64_t)i2 * n + row] * pr[2];
-      if (A.with_d2) d += A.d2[3 * (int64_t)row + a] * pr[a];
-      const double s = acc + d;
-      A.y[3 * (int64_t)row + a] = s;
-      dot += pr[a] * s;
+      if (pv) {
+        double s = 0.0;
+        for (int j = lo; j < hi; ++j) s += scr[buf][a][j];
+        const double pa = (a == 0) ? pr0 : (a == 1 ? pr1 : pr2);
+        s += h0 * pr0 + h1 * pr1 + h2 * pr2 + dd * pa;
+        A.y[3 * (int64_t)row + a] = s;
+        dot += pa * s;
+      }
+      for (int idx = tid + WG; idx < nrows * 3; idx += WG) {  // tiles of very low-degree rows (> 85 rows)
+        const int a2 = idx / nrows, row2 = r0 + (idx - a2 * nrows);
+        const int lo2 = A.inc_ptr[row2] - q0, hi2 = A.inc_ptr[row2 + 1] - q0;
+        double s = 0.0;
+        for (int j = lo2; j < hi2; ++j) s += scr[buf][a2][j];
+        const double* pr = A.p + PS * (int64_t)(A.lo + row2);
+        const int i1 = (a2 == 0) ? 1 : (a2 == 1 ? 3 : 4), i2 = (a2 == 2) ? 5 : (a2 == 1 ? 4 : 2);
+        double d = A.hd[(int64_t)a2 * n + row2] * pr[0];
+        d += A.hd[(int64_t)i1 * n + row2] * pr[1];
+        d += A.hd[(int64_t)i2 * n + row2] * pr[2];
+        if (A.with_d2) d += A.d2[3 * (int64_t)row2 + a2] * pr[a2];
+        s += d;
+        A.y[3 * (int64_t)row2 + a2] = s;
+        dot += pr[a2] * s;
+      }
+      buf ^= 1;
+    } else {
+      // ---- one heavy row (> 256 incidences): chunked, two barriers per chunk
+      double acc = 0.0;
+      for (int base = q0; base < q1; base += WG) {
+        const int q = base + tid;
+        if (q < q1) {
+          const int64_t col = A.inc_col[q];
+          const double p0 = A.p[PS * col], p1 = A.p[PS * col + 1], p2 = A.p[PS * col + 2];
+          const double* h = A.hoff + q;
+          scr[buf][0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
+          scr[buf][1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
+          scr[buf][2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
+        }
+        __syncthreads();
+        if (tid < 3) {
+          const int hi = min(q1, base + WG) - base;
+          double s = 0.0;
+          for (int j = 0; j < hi; ++j) s += scr[buf][tid][j];
+          acc += s;
+        }
+        __syncthreads();
+      }
+      if (tid < 3) {
+        const int a = tid, row = r0;
+        const double* pr = A.p + PS * (int64_t)(A.lo + row);
+        const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
+        double d = A.hd[(int64_t)a * n + row] * pr[0];
+        d += A.hd[(int64_t)i1 * n + row] * pr[1];
+        d += A.hd[(int64_t)i2 * n + row] * pr[2];
+        if (A.with_d2) d += A.d2[3 * (int64_t)row + a] * pr[a];
+        const double s = acc + d;
+        A.y[3 * (int64_t)row + a] = s;
+        dot += pr[a] * s;
+      }
     }
   }
   const double tot = block_sum_bcast(dot, red);
@@ -507,7 +589,7 @@ __global__ __launch_bounds__(WG) void k_cg_init(CgVec V, const double* __restric
     o = V.y + 3 * (int64_t)row; o[0] = 0.0; o[1] = 0.0; o[2] = 0.0;
     o = V.r + 3 * (int64_t)row; o[0] = r0; o[1] = r1; o[2] = r2;
     o = V.z + 3 * (int64_t)row; o[0] = z0; o[1] = z1; o[2] = z2;
-    o = V.p + 3 * (int64_t)(V.lo + row); o[0] = z0; o[1] = z1; o[2] = z2;
+    o = V.p + PS * (int64_t)(V.lo + row); o[0] = z0; o[1] = z1; o[2] = z2;
     rz += r0 * z0 + r1 * z1 + r2 * z2;
     bb += r0 * r0 + r1 * r1 + r2 * r2;
   }
@@ -542,7 +624,7 @@ __global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, const do
   double rz = 0.0, rr = 0.0;
   const int64_t n = V.n_loc;
   for (int row = blockIdx.x * WG + threadIdx.x; row < V.n_loc; row += gridDim.x * WG) {
-    const double* pp = V.p + 3 * (int64_t)(V.lo + row);
+    const double* pp = V.p + PS * (int64_t)(V.lo + row);
     double* yy = V.y + 3 * (int64_t)row;
     double* rp = V.r + 3 * (int64_t)row;
     const double* ap = V.ap + 3 * (int64_t)row;
@@ -590,9 +672,11 @@ __global__ __launch_bounds__(WG) void k_cg_update2(CgVec V, int parity, const do
   }
   const double beta = rz_new / rz_old;
   const int64_t n3 = 3 * (int64_t)V.n_loc;
-  double* p = V.p + 3 * (int64_t)V.lo;
-  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n3; i += (int64_t)gridDim.x * WG)
-    p[i] = V.z[i] + beta * p[i];
+  double* p = V.p + PS * (int64_t)V.lo;
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n3; i += (int64_t)gridDim.x * WG) {
+    const int64_t row = i / 3, j = PS * row + (i - 3 * row);
+    p[j] = V.z[i] + beta * p[j];
+  }
 }
 
 // partials of a.b over n doubles
@@ -607,11 +691,13 @@ __global__ __launch_bounds__(WG) void k_dot(int64_t n, const double* __restrict_
 
 __global__ void k_flag_to_double(const int* __restrict__ flag, double* __restrict__ out) { out[0] = (double)(*flag); }
 
-// copy the owned part of a local vector into a globally indexed one
+// copy the owned part of a local [n x 3] vector into the padded, globally indexed gather vector
 __global__ void k_scatter_owned(int n_loc, int lo, const double* __restrict__ src, double* __restrict__ dst) {
   const int64_t n3 = 3 * (int64_t)n_loc;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x)
-    dst[3 * (int64_t)lo + i] = src[i];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / 3;
+    dst[PS * (lo + row) + (i - 3 * row)] = src[i];
+  }
 }
 
 // candidate = x - S y on the owned rows; partials of |step|^2

@@ -104,6 +104,7 @@ struct pgo_handle {
   // collectives are skipped for a single rank unless PGO_FORCE_COLLECTIVES=1 (lets a 1-GPU box
   // exercise the RCCL calls themselves: at world == 1 they are identities)
   bool force_collectives = false;
+  int spmv_ablate = 0;  // timing-only ablations of k_spmv, set by pgo_bench_spmv from PGO_SPMV_ABLATE
   bool multi_rank() const { return comm && (comm->world > 1 || force_collectives); }
 
   template <class T>
@@ -156,8 +157,8 @@ struct pgo_handle {
     HIPC(hipMemcpyAsync(h_scal + first, scal + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, stream));
     return sync();
   }
-  int allgather(double* full) {
-    if (multi_rank()) PGOC(comm->allgather_inplace(full, (int64_t)3 * S.rows_per_rank, stream));
+  int allgather(double* full, int stride = 3) {
+    if (multi_rank()) PGOC(comm->allgather_inplace(full, (int64_t)stride * S.rows_per_rank, stream));
     return PGO_OK;
   }
 
@@ -235,7 +236,13 @@ struct pgo_handle {
     return A;
   }
   int spmv_enqueue(const double* p, double* yout, double* dot_part, int with_d2, const int32_t* done) {
-    hipLaunchKernelGGL(dev::k_spmv, dim3(g_spmv), dim3(dev::WG), 0, stream, spmv_args(p, yout, dot_part, with_d2, done));
+    dev::SpmvArgs A = spmv_args(p, yout, dot_part, with_d2, done);
+    switch (spmv_ablate) {
+      case 1: hipLaunchKernelGGL(dev::k_spmv_t<1>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
+      case 2: hipLaunchKernelGGL(dev::k_spmv_t<2>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
+      case 3: hipLaunchKernelGGL(dev::k_spmv_t<3>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
+      default: hipLaunchKernelGGL(dev::k_spmv_t<0>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+    }
     return check_launch("k_spmv");
   }
 
@@ -279,7 +286,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(dalloc(&poses, 3 * n_full));
   PGOC(dalloc(&cand, 3 * n_full));
   PGOC(dalloc(&scale, 3 * n_full));
-  PGOC(dalloc(&p_full, 3 * n_full));
+  PGOC(dalloc(&p_full, dev::PS * n_full));
   PGOC(dalloc(&e_ia, EL));
   PGOC(dalloc(&e_ib, EL));
   PGOC(dalloc(&e_mx, EL));
@@ -307,13 +314,14 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   HIPC(hipHostMalloc((void**)&h_scal, N_SCAL * sizeof(double)));
 
   auto cdiv = [](int64_t a, int64_t b) { return (int)((a + b - 1) / b); };
-  g_edge = std::max(1, cdiv(EL, dev::WG));
+  auto up8 = [](int g) { return ((g + 7) / 8) * 8; };  // XCD-aware kernels need gridDim % 8 == 0
+  g_edge = up8(std::max(1, cdiv(EL, dev::WG)));
   g_rows = std::max(1, cdiv(NL, dev::WG));
   g_vec = std::min(std::max(1, cdiv(NL, dev::WG)), 1024);
   g_flat = std::min(std::max(1, cdiv(3 * NL, dev::WG)), 2048);
-  g_spmv = std::min(std::max(1, S.n_tiles()), 2048);
-  g_asm = std::min(std::max(1, S.n_tiles()), 1 << 20);
-  part_cap = std::max(g_edge, 2048);
+  g_spmv = up8(std::min(std::max(1, S.n_tiles()), 2048));
+  g_asm = up8(std::min(std::max(1, S.n_tiles()), 1 << 20));
+  part_cap = std::max(g_edge, 2048) + 8;
   for (int k = 0; k < N_PART; ++k) PGOC(dalloc(&part[k], part_cap));
 
   HIPC(hipMemcpyAsync(poses, poses_h, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -410,7 +418,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
   PGOC(reduce_to_scal({{part[0], g_vec, 0}, {part[1], g_vec, 0}}, 4));
   hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
   PGOC(check_launch("k_cg_init_fin"));
-  PGOC(allgather(p_full));
+  PGOC(allgather(p_full, dev::PS));
   const int max_it = std::max(0, opt.pcg_max_iters);
   const int every = std::max(1, opt.pcg_check_every);
   int it = 0;
@@ -426,7 +434,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
         PGOC(reduce_to_scal({{part[1], g_vec, 0}, {part[2], g_vec, 0}}, 7));
         hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
         PGOC(check_launch("k_cg_update2"));
-        PGOC(allgather(p_full));
+        PGOC(allgather(p_full, dev::PS));
       } else {
         hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, part[0], g_spmv, part[1], part[2]);
         hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_vec, part[2], g_vec);
@@ -483,7 +491,7 @@ int pgo_handle::lm_iteration(bool* stop) {
   // model_cost_change = -(J d).(r + J d / 2), d = -S y   ==   y.gs - y.(H y) / 2
   hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
   PGOC(check_launch("k_scatter_owned"));
-  PGOC(allgather(p_full));
+  PGOC(allgather(p_full, dev::PS));
   PGOC(spmv_enqueue(p_full, ap, part[0], 0, nullptr));  // part[0] <- partials of y.(H y)
   hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs, part[1]);
   PGOC(check_launch("k_dot"));
@@ -791,7 +799,8 @@ int pgo_debug_spmv(pgo_t* h, const double* x, double* yout) {
   if (h->comm && h->comm->world > 1) return fail(PGO_ERR_UNSUPPORTED, "world == 1 only");
   HIPC(hipSetDevice(h->device));
   const int64_t N = h->S.n_poses;
-  HIPC(hipMemcpyAsync(h->p_full, x, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPC(hipMemcpyAsync(h->y, x, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(dev::k_scatter_owned, dim3(h->g_flat), dim3(dev::WG), 0, h->stream, h->S.n_loc, h->S.lo, h->y, h->p_full);
   PGOC(h->spmv_enqueue(h->p_full, h->ap, h->part[0], 0, nullptr));
   HIPC(hipMemcpyAsync(yout, h->ap, (size_t)3 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   return h->sync();
@@ -845,7 +854,11 @@ int pgo_bench_spmv(pgo_t* h, int reps, pgo_kernel_stats* out) {
   if (!h->lin_valid) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_spmv: call pgo_lm_begin first");
   HIPC(hipSetDevice(h->device));
   double ms = 0;
-  PGOC(time_launches(h, reps, [&] { (void)h->spmv_enqueue(h->p_full, h->ap, h->part[0], 1, nullptr); }, &ms));
+  const char* ab = getenv("PGO_SPMV_ABLATE");
+  h->spmv_ablate = ab ? atoi(ab) : 0;
+  int st_ab = time_launches(h, reps, [&] { (void)h->spmv_enqueue(h->p_full, h->ap, h->part[0], 1, nullptr); }, &ms);
+  h->spmv_ablate = 0;
+  PGOC(st_ab);
   out->ms_avg = ms;
   out->units = h->S.n_inc + h->S.n_loc;
   // 76 B per off-diagonal block (value + column) ; per row: 48 B diagonal planes + 24 B D'D + 4 B row
