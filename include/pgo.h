@@ -139,7 +139,7 @@ typedef struct pgo_options {
   int32_t pcg_max_iters;       /* cap per LM iteration                            */
   int32_t pcg_check_every;     /* iterations enqueued between host residual checks */
   int32_t verbose;             /* 1 = Ceres-like per-iteration table on stdout    */
-  int32_t use_graphs;          /* 1 = replay the CG iteration as a hipGraph       */
+  int32_t use_graphs;          /* 1 (default) = replay slices of pcg_check_every PCG iterations as a hipGraph (world == 1) */
   int32_t reserved[8];
 } pgo_options;
 

@@ -366,3 +366,16 @@ def test_cli_drop_in(pgo, tmp_path):
     edges = np.loadtxt(os.path.join(save, "opt_edges.txt"), dtype=int)
     assert edges.shape == (1533, 3) and list(np.bincount(edges[:, 2])) == [1227, 256, 50]
     assert subprocess.run([exe, "INTEL", "0", "2"], capture_output=True).returncode == 3
+
+
+def test_graph_replay_is_bitwise_identical_to_eager(pgo):
+    """slices of PCG iterations replayed from a hipGraph (default) vs launched eagerly: same kernels, same order"""
+    g = load(pgo, "INTEL", 50)
+    out = []
+    for flag in (1, 0):
+        s = pgo.Solver(g, pgo.Options(method=1, max_iters=5, use_graphs=flag, pcg_check_every=37))
+        summ = s.solve()
+        out.append((summ.final_cost, summ.total_pcg_iters, s.poses()))
+        s.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    np.testing.assert_array_equal(out[0][2], out[1][2])

@@ -83,6 +83,9 @@ struct pgo_handle {
   double* scal = nullptr;
   double* h_scal = nullptr;  // pinned
   int* bad = nullptr;
+  // captured slice of PCG iterations (world == 1)
+  hipGraphExec_t cg_graph_exec = nullptr;
+  int cg_graph_len = 0;
   // grids
   int g_edge = 1, g_rows = 1, g_vec = 1, g_flat = 1, g_spmv = 1, g_asm = 1;
 
@@ -96,6 +99,7 @@ struct pgo_handle {
   ~pgo_handle() {
     if (device >= 0) (void)hipSetDevice(device);
     for (void* p : allocs) (void)hipFree(p);
+    if (cg_graph_exec) (void)hipGraphExecDestroy(cg_graph_exec);
     if (h_st) (void)hipHostFree(h_st);
     if (h_scal) (void)hipHostFree(h_scal);
     if (stream) (void)hipStreamDestroy(stream);
@@ -420,26 +424,54 @@ int pgo_handle::pcg(int* iters, double* rel) {
   PGOC(check_launch("k_cg_init_fin"));
   PGOC(allgather(p_full, dev::PS));
   const int max_it = std::max(0, opt.pcg_max_iters);
-  const int every = std::max(1, opt.pcg_check_every);
+  int every = std::max(1, opt.pcg_check_every);
+  // one PCG iteration = 3 dependent launches; `par` is the r.z double-buffer parity baked into the arguments
+  auto enqueue_iteration = [&](int par) -> int {
+    PGOC(spmv_enqueue(p_full, ap, part[0], 1, &st->done));
+    if (multi) {
+      PGOC(reduce_to_scal({{part[0], g_spmv, 0}}, 6));
+      hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, scal + 6, 1, part[1], part[2]);
+      PGOC(check_launch("k_cg_update1"));
+      PGOC(reduce_to_scal({{part[1], g_vec, 0}, {part[2], g_vec, 0}}, 7));
+      hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
+      PGOC(check_launch("k_cg_update2"));
+      PGOC(allgather(p_full, dev::PS));
+    } else {
+      hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, part[0], g_spmv, part[1], part[2]);
+      hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_vec, part[2], g_vec);
+      PGOC(check_launch("k_cg_update"));
+    }
+    return PGO_OK;
+  };
+  // Launch-bound regime (small graphs): a slice of `every` iterations is captured ONCE per handle into a
+  // hipGraph (every argument is fixed for the handle's lifetime; the slice length is even so the parity
+  // pattern repeats) and replayed with a single host call per slice.
+  const bool use_graph = opt.use_graphs && !multi;
+  if (use_graph) {
+    every += every & 1;
+    if (!cg_graph_exec || cg_graph_len != every) {
+      if (cg_graph_exec) (void)hipGraphExecDestroy(cg_graph_exec);
+      cg_graph_exec = nullptr;
+      hipGraph_t gr = nullptr;
+      HIPC(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      int st_cap = PGO_OK;
+      for (int c = 0; c < every && st_cap == PGO_OK; ++c) st_cap = enqueue_iteration(c & 1);
+      hipError_t e_end = hipStreamEndCapture(stream, &gr);
+      PGOC(st_cap);
+      if (e_end != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end));
+      hipError_t e_inst = hipGraphInstantiate(&cg_graph_exec, gr, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(gr);
+      if (e_inst != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e_inst));
+      cg_graph_len = every;
+    }
+  }
   int it = 0;
   while (true) {
     const int chunk = std::min(every, max_it - it);
-    for (int c = 0; c < chunk; ++c) {
-      const int par = (it + c) & 1;
-      PGOC(spmv_enqueue(p_full, ap, part[0], 1, &st->done));
-      if (multi) {
-        PGOC(reduce_to_scal({{part[0], g_spmv, 0}}, 6));
-        hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, scal + 6, 1, part[1], part[2]);
-        PGOC(check_launch("k_cg_update1"));
-        PGOC(reduce_to_scal({{part[1], g_vec, 0}, {part[2], g_vec, 0}}, 7));
-        hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
-        PGOC(check_launch("k_cg_update2"));
-        PGOC(allgather(p_full, dev::PS));
-      } else {
-        hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, part[0], g_spmv, part[1], part[2]);
-        hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_vec, part[2], g_vec);
-        PGOC(check_launch("k_cg_update"));
-      }
+    if (use_graph && chunk == every && (it & 1) == 0) {
+      HIPC(hipGraphLaunch(cg_graph_exec, stream));
+    } else {
+      for (int c = 0; c < chunk; ++c) PGOC(enqueue_iteration((it + c) & 1));
     }
     it += chunk;
     HIPC(hipMemcpyAsync(h_st, st, sizeof(dev::CgState), hipMemcpyDeviceToHost, stream));
@@ -650,7 +682,7 @@ void pgo_options_default(pgo_options* o) {
   o->pcg_max_iters = 50000;
   o->pcg_check_every = 50;
   o->verbose = 0;
-  o->use_graphs = 0;
+  o->use_graphs = 1;
 }
 
 int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
