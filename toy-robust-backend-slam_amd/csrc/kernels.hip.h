@@ -2,10 +2,11 @@
 // Everything here is HBM-bandwidth bound fp64 work on 3x3 blocks: no MFMA.
 //
 //   K1  k_edge_eval      fused per-edge SE(2) residual + 3x6 Jacobian + DCS weight + Huber
-//                        corrector + Jacobi column scaling  (reference: src/ceres_error.cpp:42-94,
-//                        135-196 evaluated through AutoDiffCostFunction, main.cpp:66-68 loss)
-//   K2  k_assemble       row-tiled segmented reduction of (JS)'(JS) and S J'r into
-//                        diagonal planes + one off-diagonal 3x3 block per incidence (block CSR)
+//                        corrector (reference: src/ceres_error.cpp:42-94, 135-196 evaluated through
+//                        AutoDiffCostFunction, main.cpp:66-68 loss); writes a 112-byte record per edge
+//   K2  k_assemble       row-tiled segmented reduction of (JS)'(JS) and S J'r (S = Jacobi column
+//                        scaling) into diagonal planes + one off-diagonal 3x3 block per incidence
+//                        (block CSR)
 //   K3  k_spmv           y = ((JS)'(JS) + D'D) p on that block CSR, fused p.y partial
 //   K4  k_prepare        LM diagonal + block-Jacobi (3x3 inverse) preconditioner
 //   K5  k_cg_*           fused PCG vector updates with in-kernel dot partials
@@ -17,8 +18,13 @@ namespace pgo {
 namespace dev {
 
 constexpr int WG = 256;          // workgroup size of every kernel here (4 waves)
-constexpr int REC = 22;          // doubles per edge record: J (18, row-major 3x6) | r (3) | cost (1)
-constexpr int REC_LDS = 23;      // odd stride => conflict-free ds_write_b64 when staging records
+// Edge record, 14 doubles = 112 B (16-byte aligned):  A = d e/d P1 (9, row-major) | g2 | r (3) | cost.
+// The second Jacobian block is implied by the structure of the SE(2) error (also under DCS and the
+// Huber corrector, which scale whole rows / add e (x) grad psi with grad psi antisymmetric in (x,y)):
+//     d e/d P2 = [ -A[:,0] | -A[:,1] | (0, 0, g2)' ]
+// so storing it would only repeat 8 of its 9 entries.
+constexpr int REC = 14;
+constexpr int REC_LDS = 15;      // odd stride => conflict-free ds_write_b64 when staging records
 constexpr int PS = 3;            // doubles per pose in the GATHERED vector p.  Padding to 4 (32 B, never straddling a
                                  // 64-byte sector) was measured: no fewer fetched bytes (FETCH_SIZE 566 vs 557 MiB), so 3.
 
@@ -84,7 +90,6 @@ __device__ __forceinline__ double sum_partials_bcast(const double* __restrict__ 
 // ------------------------------------------------------------------- K1
 struct EdgeArgs {
   const double* poses;    // [.. x 3] global pose positions
-  const double* scale;    // [.. x 3] Jacobi column scales (0 on the constant pose) or nullptr = 1
   const int32_t* ia;
   const int32_t* ib;
   const double* mx;
@@ -98,7 +103,7 @@ struct EdgeArgs {
 };
 
 // One lane per edge.  Algorithmic bytes per edge: 8 (ia,ib) + 24 (meas) + 1 (flags) +
-// 48 (two poses) [+ 48 scales] read, 176 written with the Jacobian, 0 without.
+// 48 (two poses) read, 112 written with the Jacobian, 0 without.
 template <bool WITH_JAC>
 __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict__ jr,
                                                   double* __restrict__ cost_part, int* __restrict__ bad) {
@@ -174,35 +179,33 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
     if (fl & 2u) cost = ecost;
     bool finite = isfinite(s);
     if (WITH_JAC) {
-      double sa0 = 1.0, sa1 = 1.0, sa2 = 1.0, sb0 = 1.0, sb1 = 1.0, sb2 = 1.0;
-      if (A.scale) {
-        sa0 = A.scale[3 * (int64_t)a]; sa1 = A.scale[3 * (int64_t)a + 1]; sa2 = A.scale[3 * (int64_t)a + 2];
-        sb0 = A.scale[3 * (int64_t)b]; sb1 = A.scale[3 * (int64_t)b + 1]; sb2 = A.scale[3 * (int64_t)b + 2];
-      }
       double* st = stage + tid * REC_LDS;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const double v0 = sc * J[6 * i + 0], v1 = sc * J[6 * i + 1], v2 = sc * J[6 * i + 2];
-        const double v3 = sc * J[6 * i + 3], v4 = sc * J[6 * i + 4], v5 = sc * J[6 * i + 5];
-        finite = finite && isfinite(v0) && isfinite(v1) && isfinite(v2) && isfinite(v3) && isfinite(v4) && isfinite(v5);
-        st[6 * i + 0] = v0 * sa0; st[6 * i + 1] = v1 * sa1; st[6 * i + 2] = v2 * sa2;
-        st[6 * i + 3] = v3 * sb0; st[6 * i + 4] = v4 * sb1; st[6 * i + 5] = v5 * sb2;
+        finite = finite && isfinite(v0) && isfinite(v1) && isfinite(v2);
+        st[3 * i + 0] = v0;
+        st[3 * i + 1] = v1;
+        st[3 * i + 2] = v2;
       }
-      st[18] = sc * ex;
-      st[19] = sc * ey;
-      st[20] = sc * et;
-      st[21] = ecost;
+      const double g2 = sc * J[17];
+      finite = finite && isfinite(g2);
+      st[9] = g2;
+      st[10] = sc * ex;
+      st[11] = sc * ey;
+      st[12] = sc * et;
+      st[13] = ecost;
     }
     if (!finite) atomicOr(bad, 1);
   }
   if (WITH_JAC) {
-    // transpose through LDS so that the 176-byte records leave as 16-byte-per-lane
-    // coalesced stores (a lane-per-record store would touch ~90 lines per instruction)
+    // transpose through LDS so that the 112-byte records leave as 16-byte-per-lane
+    // coalesced stores (a lane-per-record store would touch ~60 lines per instruction)
     __syncthreads();
     int64_t nvalid = live ? A.n_edges - e0 : 0;
     if (nvalid > WG) nvalid = WG;
     const int ndbl = (int)nvalid * REC;
-    double* out = jr + e0 * REC;  // 16-byte aligned: e0 * 176
+    double* out = jr + e0 * REC;  // 16-byte aligned: e0 * 112
     for (int j = tid * 2; j < ndbl; j += 2 * WG) {
       const int le = j / REC, c = j - le * REC;  // REC is even => (j, j+1) stay in one record
       double2 v;
@@ -216,13 +219,27 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
 }
 
 // ------------------------------------------------------------------- K2
+// local row (in [r0, r1)) whose incidence range contains q: binary search in inc_ptr (<= 8 steps, L1/L2 hits)
+__device__ __forceinline__ int upper_row(const int32_t* __restrict__ inc_ptr, int r0, int r1, int q) {
+  int lo = r0, hi = r1 - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (inc_ptr[mid] <= q) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
 struct AsmArgs {
   const double* jr;          // edge records
   const int32_t* inc_ptr;    // n_loc + 1
   const int32_t* inc_edge;   // (local edge << 1) | side
+  const int32_t* inc_col;    // global pose position of the other endpoint
   const int32_t* tile_row;   // n_tiles + 1 (local rows)
+  const double* scale;       // [.. x 3] Jacobi column scales, global pose positions (0 on the constant pose)
   int32_t n_tiles;
   int32_t n_loc;
+  int32_t lo;                // first owned global row
   int64_t inc_stride;        // plane stride of hoff (>= n_inc)
   double* hoff;              // 9 planes [inc_stride]: (J_self)'(J_other), row-major 3x3
   double* hd;                // 6 planes [n_loc]: d00 d01 d02 d11 d12 d22 of (J_self)'(J_self) summed
@@ -249,6 +266,7 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
       const int q = base + tid;
       if (q < q1) {
         const int ed = A.inc_edge[q];
+        const int64_t col = A.inc_col[q];
         const double2* rp = reinterpret_cast<const double2*>(A.jr + (int64_t)(ed >> 1) * REC);
         double R[REC];
 #pragma unroll
@@ -257,16 +275,28 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
           R[2 * k] = v.x;
           R[2 * k + 1] = v.y;
         }
-        const int cs = (ed & 1) ? 3 : 0, co = 3 - cs;
-        double S[9], O[9];  // S[k*3+a] = J[k][cs+a]
+        // Jacobi column scales of this row's pose and of the other endpoint
+        double ss[3], so[3];
+        {
+          const int row = (int)(upper_row(A.inc_ptr, r0, r1, q));
+          const double* s_self = A.scale + 3 * (int64_t)(A.lo + row);
+          const double* s_oth = A.scale + 3 * col;
+          ss[0] = s_self[0]; ss[1] = s_self[1]; ss[2] = s_self[2];
+          so[0] = s_oth[0]; so[1] = s_oth[1]; so[2] = s_oth[2];
+        }
+        // S[k*3+a] = d e_k / d (self pose)_a * scale, O likewise for the other endpoint.
+        // side 0: self = P1 (block A), other = P2 (implied block); side 1: the reverse.
+        double S[9], O[9];
+        const bool self_is_a = (ed & 1) == 0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            S[3 * k + a] = (ed & 1) ? R[6 * k + 3 + a] : R[6 * k + a];
-            O[3 * k + a] = (ed & 1) ? R[6 * k + a] : R[6 * k + 3 + a];
-          }
-        (void)cs; (void)co;
+        for (int k = 0; k < 3; ++k) {
+          const double a0 = R[3 * k], a1 = R[3 * k + 1], a2 = R[3 * k + 2];
+          const double b2 = (k == 2) ? R[9] : 0.0;
+          const double x0 = self_is_a ? a0 : -a0, x1 = self_is_a ? a1 : -a1, x2 = self_is_a ? a2 : b2;
+          const double y0 = self_is_a ? -a0 : a0, y1 = self_is_a ? -a1 : a1, y2 = self_is_a ? b2 : a2;
+          S[3 * k] = x0 * ss[0]; S[3 * k + 1] = x1 * ss[1]; S[3 * k + 2] = x2 * ss[2];
+          O[3 * k] = y0 * so[0]; O[3 * k + 1] = y1 * so[1]; O[3 * k + 2] = y2 * so[2];
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -278,9 +308,9 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
         scr[3][tid] = S[1] * S[1] + S[4] * S[4] + S[7] * S[7];
         scr[4][tid] = S[1] * S[2] + S[4] * S[5] + S[7] * S[8];
         scr[5][tid] = S[2] * S[2] + S[5] * S[5] + S[8] * S[8];
-        scr[6][tid] = S[0] * R[18] + S[3] * R[19] + S[6] * R[20];
-        scr[7][tid] = S[1] * R[18] + S[4] * R[19] + S[7] * R[20];
-        scr[8][tid] = S[2] * R[18] + S[5] * R[19] + S[8] * R[20];
+        scr[6][tid] = S[0] * R[10] + S[3] * R[11] + S[6] * R[12];
+        scr[7][tid] = S[1] * R[10] + S[4] * R[11] + S[7] * R[12];
+        scr[8][tid] = S[2] * R[10] + S[5] * R[11] + S[8] * R[12];
       }
       __syncthreads();
       for (int idx = tid; idx < nrows * 9; idx += WG) {

@@ -167,10 +167,9 @@ struct pgo_handle {
   }
 
   // ---- K1
-  dev::EdgeArgs edge_args(const double* x, const double* sc, int apply_loss) const {
+  dev::EdgeArgs edge_args(const double* x, int apply_loss) const {
     dev::EdgeArgs A;
     A.poses = x;
-    A.scale = sc;
     A.ia = e_ia;
     A.ib = e_ib;
     A.mx = e_mx;
@@ -183,15 +182,15 @@ struct pgo_handle {
     A.huber_delta = opt.huber_delta;
     return A;
   }
-  void launch_eval(const double* x, const double* sc, int apply_loss, bool with_jac) {
-    dev::EdgeArgs A = edge_args(x, sc, apply_loss);
+  void launch_eval(const double* x, int apply_loss, bool with_jac) {
+    dev::EdgeArgs A = edge_args(x, apply_loss);
     if (with_jac) hipLaunchKernelGGL(dev::k_edge_eval<true>, dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
     else hipLaunchKernelGGL(dev::k_edge_eval<false>, dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
   }
   // evaluates at x; on return h_scal[slot] = cost, h_scal[slot+1] = #bad flags (needs fetch by caller)
-  int eval_enqueue(const double* x, const double* sc, int apply_loss, bool with_jac, int slot) {
+  int eval_enqueue(const double* x, int apply_loss, bool with_jac, int slot) {
     HIPC(hipMemsetAsync(bad, 0, sizeof(int), stream));
-    launch_eval(x, sc, apply_loss, with_jac);
+    launch_eval(x, apply_loss, with_jac);
     PGOC(check_launch("k_edge_eval"));
     // the flag rides along as a "partial array" of length 1 after conversion to double
     hipLaunchKernelGGL(dev::k_flag_to_double, dim3(1), dim3(1), 0, stream, bad, part[4]);
@@ -204,9 +203,12 @@ struct pgo_handle {
     A.jr = jr;
     A.inc_ptr = inc_ptr;
     A.inc_edge = inc_edge;
+    A.inc_col = inc_col;
     A.tile_row = tile_row;
+    A.scale = scale;
     A.n_tiles = S.n_tiles();
     A.n_loc = S.n_loc;
+    A.lo = S.lo;
     A.inc_stride = inc_stride;
     A.hoff = hoff;
     A.hd = hd;
@@ -342,13 +344,16 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   return sync();
 }
 
-// evaluate + assemble at `poses` with the current `scale`; leaves cost/bad in h_scal[0..1]
-int pgo_handle::linearize(bool /*first*/) {
+// evaluate (K1, unscaled records) + assemble (K2, applies the current `scale`) at `poses`;
+// leaves cost/bad in h_scal[0..1]
+int pgo_handle::linearize(bool reuse_records) {
   double t0 = wall_s();
-  PGOC(eval_enqueue(poses, scale, 1, true, 0));
-  PGOC(fetch_scal(0, 2));
-  t_eval += wall_s() - t0;
-  if (h_scal[1] > 0.0 || !std::isfinite(h_scal[0])) return fail(PGO_ERR_NUMERIC, "residual/Jacobian evaluation produced non-finite values");
+  if (!reuse_records) {
+    PGOC(eval_enqueue(poses, 1, true, 0));
+    PGOC(fetch_scal(0, 2));
+    t_eval += wall_s() - t0;
+    if (h_scal[1] > 0.0 || !std::isfinite(h_scal[0])) return fail(PGO_ERR_NUMERIC, "residual/Jacobian evaluation produced non-finite values");
+  }
   t0 = wall_s();
   PGOC(assemble_enqueue());
   PGOC(sync());
@@ -377,14 +382,15 @@ int pgo_handle::lm_begin() {
   hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 0, scale);
   PGOC(check_launch("k_jacobi_scale"));
   PGOC(allgather(scale));
-  PGOC(linearize(true));
+  PGOC(linearize(false));
+  const double cost0 = h_scal[0];
   if (opt.jacobi_scaling) {
     hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 1, scale);
     PGOC(check_launch("k_jacobi_scale"));
     PGOC(allgather(scale));
-    PGOC(linearize(false));
+    PGOC(linearize(true));  // the records do not depend on the scales: re-assemble only
   }
-  cost = initial_cost = h_scal[0];
+  cost = initial_cost = cost0;
   hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
   PGOC(check_launch("k_grad_max"));
   PGOC(reduce_to_scal({{part[0], g_flat, 1}}, 2, true));
@@ -558,7 +564,7 @@ int pgo_handle::lm_iteration(bool* stop) {
   invalid_run = 0;
   t0 = wall_s();
   PGOC(allgather(cand));
-  PGOC(eval_enqueue(cand, nullptr, 1, false, 0));
+  PGOC(eval_enqueue(cand, 1, false, 0));
   PGOC(fetch_scal(0, 2));
   t_cand += wall_s() - t0;
   double cand_cost = h_scal[0];
@@ -744,7 +750,7 @@ int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss, double* cost
     h->lin_valid = false;  // the record buffer is about to be overwritten
     h->lm_active = false;
   }
-  PGOC(h->eval_enqueue(x, nullptr, apply_loss, want_jac, 0));
+  PGOC(h->eval_enqueue(x, apply_loss, want_jac, 0));
   PGOC(h->fetch_scal(0, 2));
   if (cost) *cost = h->h_scal[0];
   if (want_jac) {
@@ -755,8 +761,18 @@ int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss, double* cost
     for (int64_t k = 0; k < EL; ++k) {
       const int64_t e = h->S.orig_edge[k];
       const double* R = &rec[(size_t)k * dev::REC];
-      if (J_out) memcpy(J_out + 18 * e, R, 18 * sizeof(double));
-      if (r_out) memcpy(r_out + 3 * e, R + 18, 3 * sizeof(double));
+      if (J_out) {  // expand the implied second block: d e/d P2 = [-A[:,0] | -A[:,1] | (0,0,g2)']
+        double* Jo = J_out + 18 * e;
+        for (int i = 0; i < 3; ++i) {
+          Jo[6 * i + 0] = R[3 * i];
+          Jo[6 * i + 1] = R[3 * i + 1];
+          Jo[6 * i + 2] = R[3 * i + 2];
+          Jo[6 * i + 3] = -R[3 * i];
+          Jo[6 * i + 4] = -R[3 * i + 1];
+          Jo[6 * i + 5] = (i == 2) ? R[9] : 0.0;
+        }
+      }
+      if (r_out) memcpy(r_out + 3 * e, R + 10, 3 * sizeof(double));
     }
   }
   if (h->h_scal[1] > 0.0) return fail(PGO_ERR_NUMERIC, "non-finite residual or Jacobian");
@@ -807,7 +823,7 @@ int pgo_debug_normal_eq(pgo_t* h, double* g_out, double* hdiag_out) {
   hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(h->g_rows), dim3(dev::WG), 0, h->stream, h->hd, h->S.n_loc, h->S.lo,
                      h->opt.fixed_pose, 0, h->scale);
   PGOC(h->check_launch("k_jacobi_scale"));
-  int st = h->linearize(true);
+  int st = h->linearize(false);
   h->lin_valid = false;
   PGOC(st);
   const int64_t N = h->S.n_loc;
@@ -858,13 +874,12 @@ static int time_launches(pgo_handle* h, int reps, const std::function<void()>& l
 int pgo_bench_eval(pgo_t* h, int reps, int with_jacobian, pgo_kernel_stats* out) {
   if (!h || !out || reps < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_eval: bad argument");
   HIPC(hipSetDevice(h->device));
-  if (with_jacobian && !h->lin_valid) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_eval: call pgo_lm_begin first (needs the scale vector)");
   double ms = 0;
-  PGOC(time_launches(h, reps, [&] { h->launch_eval(h->poses, with_jacobian ? h->scale : nullptr, 1, with_jacobian != 0); }, &ms));
+  PGOC(time_launches(h, reps, [&] { h->launch_eval(h->poses, 1, with_jacobian != 0); }, &ms));
   out->ms_avg = ms;
   out->units = h->S.n_edges_local;
-  // 84 B read + 176 B written per edge with the Jacobian; 84 + 8 without
-  out->algorithmic_bytes = (double)h->S.n_edges_local * (with_jacobian ? 260.0 : 92.0);
+  // 84 B read per edge + the record (here 112 B: DESIGN.md section 2); 84 + 8 without
+  out->algorithmic_bytes = (double)h->S.n_edges_local * (with_jacobian ? 196.0 : 92.0);
   return PGO_OK;
 }
 
@@ -876,8 +891,9 @@ int pgo_bench_assemble(pgo_t* h, int reps, pgo_kernel_stats* out) {
   PGOC(time_launches(h, reps, [&] { (void)h->assemble_enqueue(); }, &ms));
   out->ms_avg = ms;
   out->units = h->S.n_edges_local;
-  // every record read once (176 B/edge); per incidence 4 B index + 72 B block written; per row 72 B out + 4 B pointer
-  out->algorithmic_bytes = 176.0 * h->S.n_edges_local + 76.0 * (double)h->S.n_inc + 76.0 * h->S.n_loc;
+  // every record read once (112 B/edge); per incidence 8 B indices + 72 B block written; per row 72 B out + 4 B
+  // pointer + 24 B scale
+  out->algorithmic_bytes = 112.0 * h->S.n_edges_local + 80.0 * (double)h->S.n_inc + 100.0 * h->S.n_loc;
   return PGO_OK;
 }
 
