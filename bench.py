@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--pcg-rtol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=500)
     ap.add_argument("--kernel-reps", type=int, default=20)
-    ap.add_argument("--cpu-iters", type=int, default=1, help="LM iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=4, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
     ap.add_argument("--verbose", type=int, default=0)
     args = ap.parse_args()
