@@ -28,6 +28,12 @@ constexpr int REC_LDS = 15;      // odd stride => conflict-free ds_write_b64 whe
 constexpr int PS = 3;            // doubles per pose in the GATHERED vector p.  Padding to 4 (32 B, never straddling a
                                  // 64-byte sector) was measured: no fewer fetched bytes (FETCH_SIZE 566 vs 557 MiB), so 3.
 
+// ------------------------------------------------- layout of the off-diagonal blocks
+// AoSoA: incidences in groups of 64 (one wave), 9 values x 64 lanes contiguous (4608 B per group), so
+// that a wave's 9 coalesced 512-byte accesses fall into ONE contiguous 4.5 KiB region instead of nine
+// regions tens of MB apart (DRAM page locality; measured against plain planes).
+__device__ __forceinline__ int64_t hoff_index(int c, int64_t q) { return (q >> 6) * 576 + (int64_t)c * 64 + (q & 63); }
+
 // ------------------------------------------------- XCD-aware work mapping
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD; speed only, never
 // correctness).  Each XCD has its own 4 MiB L2, so consecutive tiles -- which gather the same pose /
@@ -241,7 +247,7 @@ struct AsmArgs {
   int32_t n_loc;
   int32_t lo;                // first owned global row
   int64_t inc_stride;        // plane stride of hoff (>= n_inc)
-  double* hoff;              // 9 planes [inc_stride]: (J_self)'(J_other), row-major 3x3
+  double* hoff;              // [(n_inc+63)/64][9][64]: (J_self)'(J_other), row-major 3x3, see hoff_index
   double* hd;                // 6 planes [n_loc]: d00 d01 d02 d11 d12 d22 of (J_self)'(J_self) summed
   double* gs;                // [n_loc x 3]: sum (J_self)' r
 };
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
         for (int a = 0; a < 3; ++a)
 #pragma unroll
           for (int b = 0; b < 3; ++b)
-            A.hoff[(int64_t)(3 * a + b) * A.inc_stride + q] = S[a] * O[b] + S[3 + a] * O[3 + b] + S[6 + a] * O[6 + b];
+            A.hoff[hoff_index(3 * a + b, q)] = S[a] * O[b] + S[3 + a] * O[3 + b] + S[6 + a] * O[6 + b];
         scr[0][tid] = S[0] * S[0] + S[3] * S[3] + S[6] * S[6];
         scr[1][tid] = S[0] * S[1] + S[3] * S[4] + S[6] * S[7];
         scr[2][tid] = S[0] * S[2] + S[3] * S[5] + S[6] * S[8];
@@ -349,7 +355,7 @@ struct SpmvArgs {
   int32_t lo;                // first owned global row
   int32_t with_d2;
   int64_t inc_stride;
-  const double* hoff;        // 9 planes
+  const double* hoff;        // AoSoA, see hoff_index
   const double* hd;          // 6 planes
   const double* d2;          // [n_loc x 3] LM diagonal D'D
   const double* p;           // gathered vector, GLOBAL indexing [.. x 3]
@@ -372,7 +378,8 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   if (A.done && *A.done) return;
   double dot = 0.0;
   int buf = 0;
-  const int64_t n = A.n_loc, S = A.inc_stride;
+  const int64_t n = A.n_loc;
+  constexpr int64_t S = 64;  // value stride inside a 64-incidence group (hoff_index)
   const XcdRange xr = xcd_range(A.n_tiles);
   for (int t = xr.begin; t < xr.end; t += xr.step) {
     const int r0 = A.tile_row[t], r1 = A.tile_row[t + 1];
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         } else {
           p0 = A.p[PS * col]; p1 = A.p[PS * col + 1]; p2 = A.p[PS * col + 2];
         }
-        const double* h = A.hoff + q;
+        const double* h = A.hoff + hoff_index(0, q);
         if (MODE == 2 || MODE == 3) {
           scr[buf][0][tid] = p0 + 2.0 * p1 + 3.0 * p2;
           scr[buf][1][tid] = p0 - p1;
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         if (q < q1) {
           const int64_t col = A.inc_col[q];
           const double p0 = A.p[PS * col], p1 = A.p[PS * col + 1], p2 = A.p[PS * col + 2];
-          const double* h = A.hoff + q;
+          const double* h = A.hoff + hoff_index(0, q);
           scr[buf][0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
           scr[buf][1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
           scr[buf][2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;

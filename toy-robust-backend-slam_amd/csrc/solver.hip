@@ -286,8 +286,8 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   n_full = (int64_t)world * S.rows_per_rank;
   const int64_t EL = S.n_edges_local, NL = S.n_loc;
-  inc_stride = ((S.n_inc + 1) / 2) * 2;  // keep planes 16-byte aligned
-  if (inc_stride == 0) inc_stride = 2;
+  inc_stride = ((S.n_inc + 63) / 64) * 64;  // whole 64-incidence groups (dev::hoff_index)
+  if (inc_stride == 0) inc_stride = 64;
 
   PGOC(dalloc(&poses, 3 * n_full));
   PGOC(dalloc(&cand, 3 * n_full));
