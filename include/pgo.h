@@ -140,7 +140,11 @@ typedef struct pgo_options {
   int32_t pcg_check_every;     /* iterations enqueued between host residual checks */
   int32_t verbose;             /* 1 = Ceres-like per-iteration table on stdout    */
   int32_t use_graphs;          /* 1 (default) = replay slices of pcg_check_every PCG iterations as a hipGraph (world == 1) */
-  int32_t reserved[8];
+  int32_t pcg_block_poses;     /* poses per block of the block-Jacobi preconditioner: 1 = the 3x3 pose blocks,
+                                  2..32 = dense (3B x 3B) blocks of B consecutive poses (explicit inverses);
+                                  0 = auto (32 for graphs of <= 8192 poses, which are launch-latency bound and
+                                  chain-like, else 1) */
+  int32_t reserved[7];
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */

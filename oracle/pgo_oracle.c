@@ -316,7 +316,7 @@ typedef struct {
   int32_t method, max_iters, fixed_pose, jacobi_scaling;
   double phi, huber_delta, ftol, gtol, ptol, radius0, max_radius, min_radius, min_relative_decrease, min_lm_diagonal,
       max_lm_diagonal, pcg_rtol;
-  int32_t pcg_max_iters, threads, verbose, _pad;
+  int32_t pcg_max_iters, threads, verbose, block_poses; /* block_poses: poses per block-Jacobi block (<=1: 3x3) */
 } oracle_options;
 
 typedef struct {
@@ -347,6 +347,8 @@ typedef struct {
   double* Hoff; /* n_inc x 9: (J_self * S_self)^T (J_other * S_other) */
   double* Minv; /* N x 9 */
   double* D2;   /* 3N */
+  int B;        /* poses per preconditioner block; > 1: dense Cholesky factors in Lg */
+  double* Lg;   /* n_groups x nb x nb (lower Cholesky factors), nb = 3B */
 } normal_eq;
 
 static void build_incidence(normal_eq* Q) {
@@ -385,6 +387,7 @@ static void free_normal_eq(normal_eq* Q) {
   free(Q->Hoff);
   free(Q->Minv);
   free(Q->D2);
+  free(Q->Lg);
 }
 
 /* H = (J S)^T (J S), gs = S J^T r ; s: 3N column scales (0 on the fixed pose) */
@@ -440,6 +443,69 @@ static void inv3_sym(const double* A, double* R) {
   R[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 
+/* dense Cholesky factors of the diagonal blocks of (H + D2) over groups of B consecutive poses */
+static void factor_groups(normal_eq* Q, int threads) {
+  int N = Q->N, B = Q->B, nb = 3 * B, ng = (N + B - 1) / B;
+  if (!Q->Lg) Q->Lg = (double*)malloc((size_t)ng * nb * nb * sizeof(double));
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+  for (int g = 0; g < ng; ++g) {
+    double* M = Q->Lg + (size_t)g * nb * nb;
+    int g0 = g * B, g1 = g0 + B < N ? g0 + B : N;
+    memset(M, 0, (size_t)nb * nb * sizeof(double));
+    for (int i = 3 * (g1 - g0); i < nb; ++i) M[i * nb + i] = 1.0;
+    for (int row = g0; row < g1; ++row) {
+      int r = 3 * (row - g0);
+      for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) M[(r + a) * nb + r + b] = Q->Hd[9 * (size_t)row + 3 * a + b];
+        M[(r + a) * nb + r + a] += Q->D2[3 * (size_t)row + a];
+      }
+      for (int q = Q->inc_ptr[row]; q < Q->inc_ptr[row + 1]; ++q) {
+        int col = Q->inc_col[q];
+        if (col < g0 || col >= g1) continue;
+        const double* ho = Q->Hoff + 9 * (size_t)q;
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) M[(r + a) * nb + 3 * (col - g0) + b] += ho[3 * a + b];
+      }
+    }
+    for (int j = 0; j < nb; ++j) { /* in-place lower Cholesky */
+      double d = M[j * nb + j];
+      for (int k = 0; k < j; ++k) d -= M[j * nb + k] * M[j * nb + k];
+      d = sqrt(d);
+      M[j * nb + j] = d;
+      for (int i = j + 1; i < nb; ++i) {
+        double v = M[i * nb + j];
+        for (int k = 0; k < j; ++k) v -= M[i * nb + k] * M[j * nb + k];
+        M[i * nb + j] = v / d;
+      }
+    }
+  }
+}
+
+static void apply_groups(const normal_eq* Q, const double* r, double* z, int threads) {
+  int N = Q->N, B = Q->B, nb = 3 * B, ng = (N + B - 1) / B;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+  for (int g = 0; g < ng; ++g) {
+    const double* L = Q->Lg + (size_t)g * nb * nb;
+    int g0 = g * B, g1 = g0 + B < N ? g0 + B : N, m = 3 * (g1 - g0);
+    double w[96];
+    for (int i = 0; i < m; ++i) {
+      double v = r[3 * (size_t)g0 + i];
+      for (int k = 0; k < i; ++k) v -= L[i * nb + k] * w[k];
+      w[i] = v / L[i * nb + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+      double v = w[i];
+      for (int k = i + 1; k < m; ++k) v -= L[k * nb + i] * w[k];
+      w[i] = v / L[i * nb + i];
+    }
+    for (int i = 0; i < m; ++i) z[3 * (size_t)g0 + i] = w[i];
+  }
+}
+
 /* y = (H + D2) x */
 static void spmv(const normal_eq* Q, const double* x, double* y, int with_d2, int threads) {
   int N = Q->N;
@@ -476,6 +542,10 @@ static double dot(const double* a, const double* b, size_t n, int threads) {
 
 static void apply_minv(const normal_eq* Q, const double* r, double* z, int threads) {
   int N = Q->N;
+  if (Q->B > 1) {
+    apply_groups(Q, r, z, threads);
+    return;
+  }
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(threads) schedule(static)
 #endif
@@ -541,6 +611,7 @@ int pgo_oracle_lm_pcg(int N, double* poses, int E, const int32_t* ia, const int3
   Q.E = E;
   Q.ia = ia;
   Q.ib = ib;
+  Q.B = (o->block_poses > 1) ? (o->block_poses > 32 ? 32 : o->block_poses) : 1;
   build_incidence(&Q);
   double* r = (double*)malloc((size_t)E * 3 * sizeof(double));
   double* J = (double*)malloc((size_t)E * 18 * sizeof(double));
@@ -633,6 +704,7 @@ int pgo_oracle_lm_pcg(int N, double* poses, int E, const int32_t* ia, const int3
       }
       inv3_sym(A, Q.Minv + 9 * (size_t)i);
     }
+    if (Q.B > 1) factor_groups(&Q, threads);
     t0 = now_s();
     double rel = 0.0;
     int k = pcg(&Q, gs, y, o->pcg_rtol, o->pcg_max_iters, &rel, w, threads);

@@ -379,3 +379,24 @@ def test_graph_replay_is_bitwise_identical_to_eager(pgo):
         s.close()
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("name,n_out", [("INTEL", 50), ("MIT", 0), ("FRH", 0)])
+def test_pose_block_jacobi_sizes_agree(pgo, oracle, name, n_out):
+    """block-Jacobi with blocks of B poses (dense explicit inverses) vs the 3x3 pose blocks: same LM
+    trajectory, far fewer PCG iterations on chain-like graphs; the C port implements the same blocks."""
+    g = load(pgo, name, n_out)
+    og = oracle_graph(oracle, g)
+    res = {}
+    for B in (1, 5, 32):
+        s = pgo.Solver(g, pgo.Options(method=1, max_iters=6, pcg_rtol=1e-11, pcg_max_iters=200000, pcg_block_poses=B))
+        summ = s.solve()
+        res[B] = (summ.final_cost, s.poses(), summ.total_pcg_iters)
+        s.close()
+    for B in (5, 32):
+        assert res[B][0] == pytest.approx(res[1][0], rel=1e-8)
+        assert np.abs(res[B][1] - res[1][1]).max() < 2e-6
+    assert res[32][2] < 0.5 * res[1][2] and res[5][2] < res[1][2]
+    port = oracle.lm_pcg(og, oracle.Options(method=1, max_iters=6, pcg_rtol=1e-11, pcg_max_iters=200000, pcg_block_poses=32, threads=4))
+    assert abs(port.total_pcg_iters - res[32][2]) <= max(5, 0.1 * res[32][2])
+    assert np.abs(port.poses - res[32][1]).max() < 2e-6

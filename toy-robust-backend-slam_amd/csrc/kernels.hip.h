@@ -716,6 +716,169 @@ __global__ __launch_bounds__(WG) void k_cg_update2(CgVec V, int parity, const do
   }
 }
 
+// ------------------------------------------------- block-Jacobi with blocks of B poses
+// The preconditioner M = blockdiag(A) over groups of B consecutive poses (nb = 3B unknowns, B <= 32).
+// A group's block holds the 3x3 diagonal blocks, the LM diagonal and every off-diagonal block whose two
+// poses fall in the group (the odometry chain and short loops).  M is SPD (a principal block-diagonal part
+// of an SPD matrix).  Its blocks are inverted EXPLICITLY once per LM iteration (Gauss-Jordan in LDS, no
+// pivoting needed for SPD), so applying it inside PCG is a dense, fully parallel mat-vec -- no sequential
+// triangular solves in the latency-critical loop.
+struct GroupPre {
+  const double* ginv;  // [n_groups][nb][nb], symmetric
+  int32_t B, nb, nb_pad, n_groups;
+};
+
+struct GroupPrepArgs {
+  const int32_t* inc_ptr;
+  const int32_t* inc_col;
+  const double* hoff;
+  const double* hd;   // 6 planes
+  const double* d2;   // [n_loc x 3]
+  double* ginv;
+  int32_t n_loc, lo, B, nb, n_groups;
+};
+
+__global__ __launch_bounds__(WG) void k_prepare_groups(GroupPrepArgs A) {
+  extern __shared__ double M[];  // nb x (nb + 1)
+  const int tid = threadIdx.x, nb = A.nb, ld = nb + 1;
+  const int64_t n = A.n_loc;
+  for (int g = blockIdx.x; g < A.n_groups; g += gridDim.x) {
+    const int g0 = g * A.B, g1 = min(A.n_loc, g0 + A.B);  // local rows of the group
+    const int valid = 3 * (g1 - g0);
+    for (int i = tid; i < nb * ld; i += WG) M[i] = 0.0;
+    __syncthreads();
+    // diagonal 3x3 blocks + LM diagonal; identity on the padding of a short last group
+    for (int i = tid; i < nb; i += WG) {
+      if (i >= valid) {
+        M[i * ld + i] = 1.0;
+      } else {
+        const int row = g0 + i / 3, a = i % 3;
+        static const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+        const int base = i - a;
+        for (int b = 0; b < 3; ++b) M[i * ld + base + b] = A.hd[(int64_t)sym[a][b] * n + row] + (a == b ? A.d2[3 * (int64_t)row + a] : 0.0);
+      }
+    }
+    __syncthreads();
+    // off-diagonal blocks whose column pose lies in the same group
+    const int q0 = A.inc_ptr[g0], q1 = A.inc_ptr[g1];
+    for (int q = q0 + tid; q < q1; q += WG) {
+      const int col = A.inc_col[q] - A.lo;
+      if (col >= g0 && col < g1) {
+        const int row = upper_row(A.inc_ptr, g0, g1, q);
+        const double* h = A.hoff + hoff_index(0, q);
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b)
+            atomicAdd(&M[(3 * (row - g0) + a) * ld + 3 * (col - g0) + b], h[(3 * a + b) * 64]);  // duplicates of a pair add up
+      }
+    }
+    __syncthreads();
+    // in-place Gauss-Jordan inverse
+    for (int k = 0; k < nb; ++k) {
+      const double pinv = 1.0 / M[k * ld + k];
+      __syncthreads();
+      for (int j = tid; j < nb; j += WG) M[k * ld + j] = (j == k) ? pinv : M[k * ld + j] * pinv;
+      __syncthreads();
+      for (int e = tid; e < nb * nb; e += WG) {
+        const int i = e / nb, j = e - i * nb;
+        if (i != k && j != k) M[i * ld + j] -= M[i * ld + k] * M[k * ld + j];
+      }
+      __syncthreads();
+      for (int i = tid; i < nb; i += WG)
+        if (i != k) M[i * ld + k] = -M[i * ld + k] * pinv;
+      __syncthreads();
+    }
+    double* out = A.ginv + (int64_t)g * nb * nb;
+    for (int e = tid; e < nb * nb; e += WG) {
+      const int i = e / nb, j = e - i * nb;
+      out[e] = 0.5 * (M[i * ld + j] + M[j * ld + i]);  // keep it exactly symmetric
+    }
+    __syncthreads();
+  }
+}
+
+// z = M^-1 r for the groups of this workgroup: r staged in LDS, one thread per unknown
+__device__ __forceinline__ double group_apply(const GroupPre& G, int g, int slot, int k, const double* rb) {
+  const double* m = G.ginv + (int64_t)g * G.nb * G.nb + k;
+  const double* r = rb + slot * G.nb_pad;
+  double z = 0.0;
+  for (int j = 0; j < G.nb; ++j) z += m[(int64_t)j * G.nb] * r[j];
+  return z;
+}
+
+__global__ __launch_bounds__(WG) void k_cg_init_g(CgVec V, GroupPre G, const double* __restrict__ b,
+                                                  double* __restrict__ part_rz, double* __restrict__ part_bb) {
+  __shared__ double rb[WG];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  const int gpw = WG / G.nb_pad, slot = tid / G.nb_pad, k = tid - slot * G.nb_pad;
+  const int64_t n3 = 3 * (int64_t)V.n_loc;
+  double rz = 0.0, bb = 0.0;
+  for (int gbase = blockIdx.x * gpw; gbase < G.n_groups; gbase += gridDim.x * gpw) {
+    const int g = gbase + slot;
+    const int64_t idx = (int64_t)g * G.nb + k;
+    const bool active = slot < gpw && g < G.n_groups && k < G.nb && idx < n3;
+    double r = 0.0;
+    if (active) r = b[idx];
+    rb[tid] = r;
+    __syncthreads();
+    if (active) {
+      const double z = group_apply(G, g, slot, k, rb);
+      V.y[idx] = 0.0;
+      V.r[idx] = r;
+      V.z[idx] = z;
+      V.p[3 * (int64_t)V.lo + idx] = z;
+      rz += r * z;
+      bb += r * r;
+    }
+    __syncthreads();
+  }
+  rz = block_sum_bcast(rz, red);
+  bb = block_sum_bcast(bb, red);
+  if (tid == 0) {
+    part_rz[blockIdx.x] = rz;
+    part_bb[blockIdx.x] = bb;
+  }
+}
+
+__global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int parity, const double* __restrict__ part_pap,
+                                                     int n_pap, double* __restrict__ part_rz, double* __restrict__ part_rr) {
+  __shared__ double rb[WG];
+  __shared__ double red[8];
+  if (V.st->done) return;
+  const int tid = threadIdx.x;
+  const double pap = sum_partials_bcast(part_pap, n_pap, red);
+  const double alpha = V.st->rz[parity] / pap;
+  const int gpw = WG / G.nb_pad, slot = tid / G.nb_pad, k = tid - slot * G.nb_pad;
+  const int64_t n3 = 3 * (int64_t)V.n_loc;
+  double rz = 0.0, rr = 0.0;
+  for (int gbase = blockIdx.x * gpw; gbase < G.n_groups; gbase += gridDim.x * gpw) {
+    const int g = gbase + slot;
+    const int64_t idx = (int64_t)g * G.nb + k;
+    const bool active = slot < gpw && g < G.n_groups && k < G.nb && idx < n3;
+    double r = 0.0;
+    if (active) {
+      V.y[idx] += alpha * V.p[3 * (int64_t)V.lo + idx];
+      r = V.r[idx] - alpha * V.ap[idx];
+      V.r[idx] = r;
+    }
+    rb[tid] = r;
+    __syncthreads();
+    if (active) {
+      const double z = group_apply(G, g, slot, k, rb);
+      V.z[idx] = z;
+      rz += r * z;
+      rr += r * r;
+    }
+    __syncthreads();
+  }
+  rz = block_sum_bcast(rz, red);
+  rr = block_sum_bcast(rr, red);
+  if (tid == 0) {
+    part_rz[blockIdx.x] = rz;
+    part_rr[blockIdx.x] = rr;
+  }
+}
+
 // partials of a.b over n doubles
 __global__ __launch_bounds__(WG) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
                                             double* __restrict__ part) {

@@ -83,6 +83,10 @@ struct pgo_handle {
   double* scal = nullptr;
   double* h_scal = nullptr;  // pinned
   int* bad = nullptr;
+  // block-Jacobi over groups of B poses (B > 1): explicit dense inverses
+  int grp_B = 1, grp_nb = 3, grp_pad = 32, n_groups = 0, g_grp = 1;
+  size_t grp_lds = 0;
+  double* ginv = nullptr;
   // captured slice of PCG iterations (world == 1)
   hipGraphExec_t cg_graph_exec = nullptr;
   int cg_graph_len = 0;
@@ -341,6 +345,24 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(upload(inc_edge, S.inc_edge));
   PGOC(upload(inc_col, S.inc_col));
   PGOC(upload(tile_row, S.tile_row));
+  // preconditioner block size
+  grp_B = opt.pcg_block_poses;
+  if (grp_B <= 0) grp_B = (N <= 8192) ? 32 : 1;
+  grp_B = std::min(grp_B, 32);
+  if (grp_B > 1 && NL > 0) {
+    grp_nb = 3 * grp_B;
+    grp_pad = ((grp_nb + 31) / 32) * 32;
+    n_groups = (int)((NL + grp_B - 1) / grp_B);
+    const int gpw = dev::WG / grp_pad;
+    g_grp = std::min(std::max(1, (n_groups + gpw - 1) / gpw), 2048);
+    grp_lds = (size_t)grp_nb * (grp_nb + 1) * sizeof(double);
+    PGOC(dalloc(&ginv, (int64_t)n_groups * grp_nb * grp_nb));
+    if (grp_lds > 48 * 1024)
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_prepare_groups), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)grp_lds));
+  } else {
+    grp_B = 1;
+  }
   return sync();
 }
 
@@ -423,9 +445,18 @@ int pgo_handle::lm_begin() {
 int pgo_handle::pcg(int* iters, double* rel) {
   dev::CgVec V = cg_vec();
   const bool multi = multi_rank();
-  hipLaunchKernelGGL(dev::k_cg_init, dim3(g_vec), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
+  dev::GroupPre GP;
+  GP.ginv = ginv;
+  GP.B = grp_B;
+  GP.nb = grp_nb;
+  GP.nb_pad = grp_pad;
+  GP.n_groups = n_groups;
+  const bool grouped = grp_B > 1;
+  const int g_u1 = grouped ? g_grp : g_vec;  // grid (= number of partials) of the init / update1 kernels
+  if (grouped) hipLaunchKernelGGL(dev::k_cg_init_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, (const double*)gs, part[0], part[1]);
+  else hipLaunchKernelGGL(dev::k_cg_init, dim3(g_u1), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
   PGOC(check_launch("k_cg_init"));
-  PGOC(reduce_to_scal({{part[0], g_vec, 0}, {part[1], g_vec, 0}}, 4));
+  PGOC(reduce_to_scal({{part[0], g_u1, 0}, {part[1], g_u1, 0}}, 4));
   hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
   PGOC(check_launch("k_cg_init_fin"));
   PGOC(allgather(p_full, dev::PS));
@@ -434,18 +465,20 @@ int pgo_handle::pcg(int* iters, double* rel) {
   // one PCG iteration = 3 dependent launches; `par` is the r.z double-buffer parity baked into the arguments
   auto enqueue_iteration = [&](int par) -> int {
     PGOC(spmv_enqueue(p_full, ap, part[0], 1, &st->done));
+    const double* pap = multi ? scal + 6 : part[0];
+    const int n_pap = multi ? 1 : g_spmv;
+    if (multi) PGOC(reduce_to_scal({{part[0], g_spmv, 0}}, 6));
+    if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, par, pap, n_pap, part[1], part[2]);
+    else hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_u1), dim3(dev::WG), 0, stream, V, par, pap, n_pap, part[1], part[2]);
+    PGOC(check_launch("k_cg_update1"));
     if (multi) {
-      PGOC(reduce_to_scal({{part[0], g_spmv, 0}}, 6));
-      hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, scal + 6, 1, part[1], part[2]);
-      PGOC(check_launch("k_cg_update1"));
-      PGOC(reduce_to_scal({{part[1], g_vec, 0}, {part[2], g_vec, 0}}, 7));
+      PGOC(reduce_to_scal({{part[1], g_u1, 0}, {part[2], g_u1, 0}}, 7));
       hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
       PGOC(check_launch("k_cg_update2"));
       PGOC(allgather(p_full, dev::PS));
     } else {
-      hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, part[0], g_spmv, part[1], part[2]);
-      hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_vec, part[2], g_vec);
-      PGOC(check_launch("k_cg_update"));
+      hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_u1, part[2], g_u1);
+      PGOC(check_launch("k_cg_update2"));
     }
     return PGO_OK;
   };
@@ -520,6 +553,22 @@ int pgo_handle::lm_iteration(bool* stop) {
   hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, opt.fixed_pose, radius,
                      opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv);
   PGOC(check_launch("k_prepare"));
+  if (grp_B > 1) {
+    dev::GroupPrepArgs GA;
+    GA.inc_ptr = inc_ptr;
+    GA.inc_col = inc_col;
+    GA.hoff = hoff;
+    GA.hd = hd;
+    GA.d2 = d2;
+    GA.ginv = ginv;
+    GA.n_loc = S.n_loc;
+    GA.lo = S.lo;
+    GA.B = grp_B;
+    GA.nb = grp_nb;
+    GA.n_groups = n_groups;
+    hipLaunchKernelGGL(dev::k_prepare_groups, dim3(std::min(n_groups, 65536)), dim3(dev::WG), grp_lds, stream, GA);
+    PGOC(check_launch("k_prepare_groups"));
+  }
   int k_it = 0;
   double rel = 0.0;
   PGOC(pcg(&k_it, &rel));
