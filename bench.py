@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--poses", type=int, default=1_000_000)
     ap.add_argument("--pcg-rtol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=500)
+    ap.add_argument("--pcg-block-poses", type=int, default=4, help="poses per block-Jacobi block (GPU and CPU baseline)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--cpu-iters", type=int, default=4, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
@@ -83,7 +84,8 @@ def main():
     t_gen = time.time() - t_gen
     K, W = args.steps, args.warmup
     opt = P.Options(method=1, max_iters=W + K, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0, pcg_rtol=args.pcg_rtol,
-                    pcg_max_iters=args.pcg_max_iters, pcg_check_every=min(100, max(1, args.pcg_max_iters)), verbose=args.verbose if rank == 0 else 0)
+                    pcg_max_iters=args.pcg_max_iters, pcg_block_poses=args.pcg_block_poses,
+                    pcg_check_every=min(100, max(1, args.pcg_max_iters)), verbose=args.verbose if rank == 0 else 0)
     t_create = time.time()
     s = P.Solver(g, opt, comm, device=local_rank)
     t_create = time.time() - t_create
@@ -131,9 +133,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "synthetic Manhattan world, %d poses / %d edges (%d odometry, %d closure, %d bogus = 10%% "
-                            "outlier loops), DCS on, Huber 0.01, LM (Ceres policy) + block-Jacobi PCG rtol %.g <= %d it"
+                            "outlier loops), DCS on, Huber 0.01, LM (Ceres policy) + block-Jacobi (%d-pose blocks) PCG rtol %.g <= %d it"
                             % (g.n_poses, n_edges, g.n_edges_of_kind(0), g.n_edges_of_kind(1), g.n_edges_of_kind(2),
-                               args.pcg_rtol, args.pcg_max_iters),
+                               args.pcg_block_poses, args.pcg_rtol, args.pcg_max_iters),
                 "baseline_config": "configs[4] (synthetic 1M poses / ~4M edges, 10% outliers, sharded PCG)",
                 "parallelism": "pose-id range shards x%d" % world,
                 "seed": 20260410,
@@ -177,7 +179,8 @@ def main():
             og = O.Graph(np.array(g.pose_ids), np.array(g.poses), np.array(g.ia), np.array(g.ib), np.array(g.meas),
                          np.array(g.info), np.array(g.kind))
             oo = O.Options(method=1, max_iters=args.cpu_iters, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0,
-                           pcg_rtol=args.pcg_rtol, pcg_max_iters=args.pcg_max_iters, threads=threads)
+                           pcg_rtol=args.pcg_rtol, pcg_max_iters=args.pcg_max_iters, threads=threads,
+                           pcg_block_poses=args.pcg_block_poses)
             tc = time.perf_counter()
             ores = O.lm_pcg(og, oo)
             tc = time.perf_counter() - tc

@@ -143,7 +143,7 @@ typedef struct pgo_options {
   int32_t pcg_block_poses;     /* poses per block of the block-Jacobi preconditioner: 1 = the 3x3 pose blocks,
                                   2..32 = dense (3B x 3B) blocks of B consecutive poses (explicit inverses);
                                   0 = auto (32 for graphs of <= 8192 poses, which are launch-latency bound and
-                                  chain-like, else 1) */
+                                  chain-like, else 4) */
   int32_t reserved[7];
 } pgo_options;
 
@@ -253,9 +253,11 @@ int pgo_debug_spmv(pgo_t* h, const double* x, double* y);                       
  * g: 3N gradient J'r (unscaled), hdiag: N x 9 diagonal 3x3 blocks of J'J         */
 int pgo_debug_normal_eq(pgo_t* h, double* g_or_null, double* hdiag_or_null);      /* [gpu] */
 /* sharding plan of a graph over `world` ranks: for rank r, rows [lo, hi) and the
- * number of local edges / cut edges.  Pure host logic.                           */
+ * number of local edges / cut edges.  rows per rank = ceil(N / world) rounded up to a
+ * multiple of row_align (the solver passes its preconditioner block size, see
+ * pgo_options.pcg_block_poses; 1 = plain ceil).  Pure host logic.                */
 int pgo_shard_plan(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
-                   int world, int rank, int32_t* lo, int32_t* hi,
+                   int world, int rank, int row_align, int32_t* lo, int32_t* hi,
                    int32_t* n_local_edges, int32_t* n_cut_edges);                 /* [host] */
 
 #ifdef __cplusplus

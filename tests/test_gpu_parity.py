@@ -268,7 +268,7 @@ def test_lm_inexact_matches_port_on_synthetic_10k(pgo, oracle):
     on the GPU against the identical algorithm in the C port."""
     g = pgo.synth_manhattan(10000, 4.0, 0.10, 20260410)
     og = oracle_graph(oracle, g)
-    kw = dict(method=1, max_iters=6, pcg_rtol=0.1, pcg_max_iters=500)
+    kw = dict(method=1, max_iters=6, pcg_rtol=0.1, pcg_max_iters=500, pcg_block_poses=4)
     s = pgo.Solver(g, pgo.Options(**kw))
     summ = s.solve()
     ores = oracle.lm_pcg(og, oracle.Options(threads=8, **kw))

@@ -68,7 +68,7 @@ def test_sharded_inexact_solve_synthetic(tmp_path, world):
         np.testing.assert_array_equal(poses[r], poses[0])
         for a, b in zip(res[r]["records"], ref[0]["records"]):
             assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-8)
-            assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 1
+            assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 1  # shard boundaries are aligned to the 4-pose blocks
     assert np.abs(poses[0] - ref_poses[0]).max() < 1e-6
 
 

@@ -166,6 +166,11 @@ def test_shard_plan(pgo, world):
     assert covered == N and owned_cost == g.n_edges
     with pytest.raises(pgo.PgoError):
         pgo.shard_plan(N, ia, ib, 2, 2)
+    # boundaries aligned to the preconditioner's pose blocks
+    for align in (4, 32):
+        lo, hi, _, _ = pgo.shard_plan(N, ia, ib, world, 0, align)
+        assert lo == 0 and (hi % align == 0 or hi == N)
+        assert sum(b - a for a, b, _, _ in (pgo.shard_plan(N, ia, ib, world, r, align) for r in range(world))) == N
 
 
 # ------------------------------------------------------------------- C-ABI

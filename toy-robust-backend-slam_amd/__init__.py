@@ -165,7 +165,7 @@ def lib():
     L.pgo_bench_spmv.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
     L.pgo_debug_spmv.argtypes = [vp, dp, dp]
     L.pgo_debug_normal_eq.argtypes = [vp, dp, dp]
-    L.pgo_shard_plan.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, ip, ip, ip, ip]
+    L.pgo_shard_plan.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
     _LIB = L
     return L
 
@@ -311,11 +311,11 @@ def synth_manhattan(n_poses: int, edges_per_pose: float = 4.0, outlier_frac: flo
     return Graph(h)
 
 
-def shard_plan(n_poses, ia, ib, world, rank):
+def shard_plan(n_poses, ia, ib, world, rank, row_align=1):
     ia = np.ascontiguousarray(ia, np.int32)
     ib = np.ascontiguousarray(ib, np.int32)
     lo, hi, nl, nc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
-    _check(lib().pgo_shard_plan(n_poses, len(ia), _ip(ia), _ip(ib), world, rank, C.byref(lo), C.byref(hi),
+    _check(lib().pgo_shard_plan(n_poses, len(ia), _ip(ia), _ip(ib), world, rank, row_align, C.byref(lo), C.byref(hi),
                                 C.byref(nl), C.byref(nc)))
     return lo.value, hi.value, nl.value, nc.value
 

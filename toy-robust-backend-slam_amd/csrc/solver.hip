@@ -285,7 +285,8 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
   const char* fc = getenv("PGO_FORCE_COLLECTIVES");
   force_collectives = fc && fc[0] == '1';
-  PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, &S));
+  grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
+  PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, grp_B, &S));
   HIPC(hipSetDevice(device));
   HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   n_full = (int64_t)world * S.rows_per_rank;
@@ -346,12 +347,9 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(upload(inc_col, S.inc_col));
   PGOC(upload(tile_row, S.tile_row));
   // preconditioner block size
-  grp_B = opt.pcg_block_poses;
-  if (grp_B <= 0) grp_B = (N <= 8192) ? 32 : 1;
-  grp_B = std::min(grp_B, 32);
   if (grp_B > 1 && NL > 0) {
     grp_nb = 3 * grp_B;
-    grp_pad = ((grp_nb + 31) / 32) * 32;
+    grp_pad = grp_nb;  // lanes per group in the apply kernels (any value <= WG works: slot = tid / grp_pad)
     n_groups = (int)((NL + grp_B - 1) / grp_B);
     const int gpw = dev::WG / grp_pad;
     g_grp = std::min(std::max(1, (n_groups + gpw - 1) / gpw), 2048);

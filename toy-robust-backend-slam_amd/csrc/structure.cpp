@@ -3,7 +3,9 @@
 // SpMV kernels, and the tiling of rows into workgroup-sized pieces.
 //
 // Sharding rule (north_star: "shards by pose-id range"):
-//   rank r owns rows [r*rpr, min(N,(r+1)*rpr)), rpr = ceil(N/world).
+//   rank r owns rows [r*rpr, min(N,(r+1)*rpr)), rpr = ceil(N/world) rounded up to a multiple of
+//   `row_align` (the preconditioner's pose-block size: shard boundaries then coincide with block
+//   boundaries, so the preconditioner -- and with it the PCG iterates -- do not depend on the world size).
 //   A rank evaluates EVERY edge touching one of its rows (cut edges are evaluated
 //   on both owners - 85 bytes of input per edge - instead of exchanging 176-byte
 //   Jacobian records), so assembly needs no communication at all.  An edge's cost
@@ -16,8 +18,8 @@
 namespace pgo {
 
 int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t* ib, const double* meas,
-                          const uint8_t* kind, int method, int world, int rank, ShardStructure* S) {
-  if (N <= 0 || E < 0 || world < 1 || rank < 0 || rank >= world)
+                          const uint8_t* kind, int method, int world, int rank, int row_align, ShardStructure* S) {
+  if (N <= 0 || E < 0 || world < 1 || rank < 0 || rank >= world || row_align < 1)
     return fail(PGO_ERR_INVALID_ARG, "build_shard_structure: bad sizes");
   for (int32_t e = 0; e < E; ++e) {
     if (ia[e] < 0 || ia[e] >= N || ib[e] < 0 || ib[e] >= N)
@@ -28,7 +30,7 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
   S->n_poses = N;
   S->world = world;
   S->rank = rank;
-  S->rows_per_rank = (N + world - 1) / world;
+  S->rows_per_rank = pgo::rows_per_rank(N, world, row_align);
   S->lo = std::min<int64_t>((int64_t)rank * S->rows_per_rank, N);
   S->hi = std::min<int64_t>((int64_t)(rank + 1) * S->rows_per_rank, N);
   S->n_loc = S->hi - S->lo;
@@ -138,10 +140,11 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
 }  // namespace pgo
 
 extern "C" int pgo_shard_plan(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int world,
-                              int rank, int32_t* lo, int32_t* hi, int32_t* n_local_edges, int32_t* n_cut_edges) {
-  if (n_poses <= 0 || n_edges < 0 || world < 1 || rank < 0 || rank >= world || (n_edges && (!ia || !ib)))
+                              int rank, int row_align, int32_t* lo, int32_t* hi, int32_t* n_local_edges,
+                              int32_t* n_cut_edges) {
+  if (n_poses <= 0 || n_edges < 0 || world < 1 || rank < 0 || rank >= world || row_align < 1 || (n_edges && (!ia || !ib)))
     return pgo::fail(PGO_ERR_INVALID_ARG, "pgo_shard_plan: bad argument");
-  int32_t rpr = (n_poses + world - 1) / world;
+  int32_t rpr = pgo::rows_per_rank(n_poses, world, row_align);
   int64_t l = std::min<int64_t>((int64_t)rank * rpr, n_poses), h = std::min<int64_t>((int64_t)(rank + 1) * rpr, n_poses);
   int32_t nl = 0, nc = 0;
   for (int32_t e = 0; e < n_edges; ++e) {
