@@ -40,7 +40,7 @@ def main():
         ores = O.lm_direct(og(g), O.Options(method=method))
         odt = time.perf_counter() - t
         rows.append(dict(workload="%s +%d outliers, METHOD %d" % (name, n_out, method), poses=g.n_poses, edges=g.n_edges,
-                         policy="exact (PCG rtol 1e-10)", lm_iters=summ.iterations, pcg_iters=summ.total_pcg_iters,
+                         policy="exact (PCG rtol 1e-10, 32-pose blocks)", lm_iters=summ.iterations, pcg_iters=summ.total_pcg_iters,
                          gpu_s=dt, gpu_it_s=summ.iterations / dt, cpu_kind="oracle lm_direct (scipy SuperLU + C eval, 1 thread)",
                          cpu_s=odt, cpu_it_s=ores.iterations / odt, final_cost_gpu=summ.final_cost, final_cost_cpu=ores.final_cost,
                          max_dxy=float(np.abs(x[:, :2] - ores.poses[:, :2]).max())))
@@ -48,7 +48,7 @@ def main():
     for n in (10000, 100000, 1000000):
         g = P.synth_manhattan(n, 4.0, 0.10, 20260410)
         iters = 10
-        kw = dict(method=1, max_iters=iters, ftol=0.0, gtol=0.0, ptol=0.0, pcg_rtol=0.1, pcg_max_iters=500)
+        kw = dict(method=1, max_iters=iters, ftol=0.0, gtol=0.0, ptol=0.0, pcg_rtol=0.1, pcg_max_iters=500, pcg_block_poses=4)
         s = P.Solver(g, P.Options(pcg_check_every=100, **kw))
         s.solve()
         s.set_poses(np.array(g.poses))
@@ -63,7 +63,7 @@ def main():
         ores = O.lm_pcg(og(g), O.Options(threads=threads, **dict(kw, max_iters=cpu_iters)))
         odt = time.perf_counter() - t
         rows.append(dict(workload="synthetic Manhattan %d poses, 10%% outliers, DCS" % n, poses=g.n_poses, edges=g.n_edges,
-                         policy="inexact (eta 0.1, <= 500 PCG)", lm_iters=summ.iterations, pcg_iters=summ.total_pcg_iters,
+                         policy="inexact (eta 0.1, <= 500 PCG, 4-pose blocks)", lm_iters=summ.iterations, pcg_iters=summ.total_pcg_iters,
                          gpu_s=dt, gpu_it_s=summ.iterations / dt, cpu_kind="oracle lm_pcg (C port, %d threads)" % threads,
                          cpu_s=odt, cpu_it_s=ores.iterations / odt, final_cost_gpu=summ.final_cost,
                          final_cost_cpu=ores.final_cost, edges_per_s_k1=k1.units / (k1.ms_avg * 1e-3),

@@ -739,58 +739,73 @@ struct GroupPrepArgs {
 };
 
 __global__ __launch_bounds__(WG) void k_prepare_groups(GroupPrepArgs A) {
-  extern __shared__ double M[];  // nb x (nb + 1)
-  const int tid = threadIdx.x, nb = A.nb, ld = nb + 1;
+  extern __shared__ double Mall[];  // (WG / L) matrices of nb x (nb + 1)
+  // L lanes cooperate on one group: a whole workgroup for big blocks, one wave for small ones (nb <= 24),
+  // so that four groups share a workgroup.  Control flow is uniform (same nb everywhere): the barriers
+  // below are workgroup-wide even when the waves work on different groups.
+  const int nb = A.nb, ld = nb + 1;
+  const int L = (nb <= 24) ? 64 : WG;
+  const int sub = threadIdx.x / L, lt = threadIdx.x - sub * L, gpw = WG / L;
+  double* M = Mall + (size_t)sub * nb * ld;
   const int64_t n = A.n_loc;
-  for (int g = blockIdx.x; g < A.n_groups; g += gridDim.x) {
-    const int g0 = g * A.B, g1 = min(A.n_loc, g0 + A.B);  // local rows of the group
+  const int n_rounds = (A.n_groups + gpw - 1) / gpw;
+  for (int round = blockIdx.x; round < n_rounds; round += gridDim.x) {
+    const int g = round * gpw + sub;
+    const bool live = g < A.n_groups;
+    const int g0 = live ? g * A.B : 0, g1 = live ? min(A.n_loc, g0 + A.B) : 0;  // local rows of the group
     const int valid = 3 * (g1 - g0);
-    for (int i = tid; i < nb * ld; i += WG) M[i] = 0.0;
+    for (int i = lt; i < nb * ld; i += L) M[i] = 0.0;
     __syncthreads();
     // diagonal 3x3 blocks + LM diagonal; identity on the padding of a short last group
-    for (int i = tid; i < nb; i += WG) {
+    for (int i = lt; i < nb; i += L) {
       if (i >= valid) {
         M[i * ld + i] = 1.0;
       } else {
         const int row = g0 + i / 3, a = i % 3;
-        static const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
         const int base = i - a;
-        for (int b = 0; b < 3; ++b) M[i * ld + base + b] = A.hd[(int64_t)sym[a][b] * n + row] + (a == b ? A.d2[3 * (int64_t)row + a] : 0.0);
+        for (int b = 0; b < 3; ++b) {
+          const int pl = (a == b) ? (a == 0 ? 0 : (a == 1 ? 3 : 5)) : ((a + b == 1) ? 1 : ((a + b == 2) ? 2 : 4));
+          M[i * ld + base + b] = A.hd[(int64_t)pl * n + row] + (a == b ? A.d2[3 * (int64_t)row + a] : 0.0);
+        }
       }
     }
     __syncthreads();
     // off-diagonal blocks whose column pose lies in the same group
-    const int q0 = A.inc_ptr[g0], q1 = A.inc_ptr[g1];
-    for (int q = q0 + tid; q < q1; q += WG) {
-      const int col = A.inc_col[q] - A.lo;
-      if (col >= g0 && col < g1) {
-        const int row = upper_row(A.inc_ptr, g0, g1, q);
-        const double* h = A.hoff + hoff_index(0, q);
-        for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b)
-            atomicAdd(&M[(3 * (row - g0) + a) * ld + 3 * (col - g0) + b], h[(3 * a + b) * 64]);  // duplicates of a pair add up
+    if (live) {
+      const int q0 = A.inc_ptr[g0], q1 = A.inc_ptr[g1];
+      for (int q = q0 + lt; q < q1; q += L) {
+        const int col = A.inc_col[q] - A.lo;
+        if (col >= g0 && col < g1) {
+          const int row = upper_row(A.inc_ptr, g0, g1, q);
+          const double* h = A.hoff + hoff_index(0, q);
+          for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+              atomicAdd(&M[(3 * (row - g0) + a) * ld + 3 * (col - g0) + b], h[(3 * a + b) * 64]);  // duplicate pairs add up
+        }
       }
     }
     __syncthreads();
-    // in-place Gauss-Jordan inverse
+    // in-place Gauss-Jordan inverse (SPD: no pivoting)
     for (int k = 0; k < nb; ++k) {
       const double pinv = 1.0 / M[k * ld + k];
       __syncthreads();
-      for (int j = tid; j < nb; j += WG) M[k * ld + j] = (j == k) ? pinv : M[k * ld + j] * pinv;
+      for (int j = lt; j < nb; j += L) M[k * ld + j] = (j == k) ? pinv : M[k * ld + j] * pinv;
       __syncthreads();
-      for (int e = tid; e < nb * nb; e += WG) {
+      for (int e = lt; e < nb * nb; e += L) {
         const int i = e / nb, j = e - i * nb;
         if (i != k && j != k) M[i * ld + j] -= M[i * ld + k] * M[k * ld + j];
       }
       __syncthreads();
-      for (int i = tid; i < nb; i += WG)
+      for (int i = lt; i < nb; i += L)
         if (i != k) M[i * ld + k] = -M[i * ld + k] * pinv;
       __syncthreads();
     }
-    double* out = A.ginv + (int64_t)g * nb * nb;
-    for (int e = tid; e < nb * nb; e += WG) {
-      const int i = e / nb, j = e - i * nb;
-      out[e] = 0.5 * (M[i * ld + j] + M[j * ld + i]);  // keep it exactly symmetric
+    if (live) {
+      double* out = A.ginv + (int64_t)g * nb * nb;
+      for (int e = lt; e < nb * nb; e += L) {
+        const int i = e / nb, j = e - i * nb;
+        out[e] = 0.5 * (M[i * ld + j] + M[j * ld + i]);  // keep it exactly symmetric
+      }
     }
     __syncthreads();
   }

@@ -86,6 +86,7 @@ struct pgo_handle {
   // block-Jacobi over groups of B poses (B > 1): explicit dense inverses
   int grp_B = 1, grp_nb = 3, grp_pad = 32, n_groups = 0, g_grp = 1;
   size_t grp_lds = 0;
+  int grp_prep_grid = 1;
   double* ginv = nullptr;
   // captured slice of PCG iterations (world == 1)
   hipGraphExec_t cg_graph_exec = nullptr;
@@ -353,7 +354,9 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     n_groups = (int)((NL + grp_B - 1) / grp_B);
     const int gpw = dev::WG / grp_pad;
     g_grp = std::min(std::max(1, (n_groups + gpw - 1) / gpw), 2048);
-    grp_lds = (size_t)grp_nb * (grp_nb + 1) * sizeof(double);
+    const int prep_gpw = (grp_nb <= 24) ? dev::WG / 64 : 1;  // groups per workgroup in k_prepare_groups
+    grp_lds = (size_t)prep_gpw * grp_nb * (grp_nb + 1) * sizeof(double);
+    grp_prep_grid = std::min((n_groups + prep_gpw - 1) / prep_gpw, 65536);
     PGOC(dalloc(&ginv, (int64_t)n_groups * grp_nb * grp_nb));
     if (grp_lds > 48 * 1024)
       HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_prepare_groups), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -564,7 +567,7 @@ int pgo_handle::lm_iteration(bool* stop) {
     GA.B = grp_B;
     GA.nb = grp_nb;
     GA.n_groups = n_groups;
-    hipLaunchKernelGGL(dev::k_prepare_groups, dim3(std::min(n_groups, 65536)), dim3(dev::WG), grp_lds, stream, GA);
+    hipLaunchKernelGGL(dev::k_prepare_groups, dim3(grp_prep_grid), dim3(dev::WG), grp_lds, stream, GA);
     PGOC(check_launch("k_prepare_groups"));
   }
   int k_it = 0;
