@@ -167,3 +167,16 @@ def test_lm_policy_rejected_step_shrinks_radius(oracle):
     assert all(x >= y for x, y in zip(costs, costs[1:]))  # monotone
     for r in rej:
         assert r["relative_decrease"] <= 1e-3
+
+
+def test_lm_pcg_port_pose_blocks(oracle):
+    """block-Jacobi over groups of B poses in the port: same LM trajectory as the direct solve, fewer PCG iterations"""
+    g = oracle.read_g2o(os.path.join(DATA, "MIT.g2o"))
+    a = oracle.lm_direct(g, oracle.Options(method=1, max_iters=5))
+    its = {}
+    for B in (1, 8, 32):
+        b = oracle.lm_pcg(g, oracle.Options(method=1, max_iters=5, pcg_rtol=1e-12, pcg_max_iters=200000, threads=4,
+                                             pcg_block_poses=B))
+        assert np.abs(a.poses - b.poses).max() < 1e-7 and a.final_cost == pytest.approx(b.final_cost, rel=1e-9)
+        its[B] = b.total_pcg_iters
+    assert its[32] < its[8] < its[1]
