@@ -103,12 +103,13 @@ int pgo_write_edges(const pgo_graph* g, const char* path);                 /* [h
 int pgo_write_g2o(const pgo_graph* g, const char* path);                   /* [host] */
 
 /* Synthetic Manhattan world (BASELINE configs C4/C5; the reference ships no
- * generator -- spec in SURVEY.md section 8(d)): unit steps on the integer grid,
- * +-90 degree turns with p=0.2, odometry noise N(0, 0.02 m / 0.01 rad), up to
- * `max_loops_per_pose` closures to earlier poses (|i-j| >= 5) within 1.5 m until
- * about edges_per_pose * N edges, initial poses = dead-reckoned odometry, plus
- * round(outlier_frac * #closures) bogus loops with R4 semantics (uniform random
- * endpoints, zero measurement).  PRNG: splitmix64(seed).                          */
+ * generator -- spec in SURVEY.md section 8(d)): unit steps on the integer grid of a
+ * bounded square (side ~ sqrt(N/4), so cells are revisited), +-90 degree turns with
+ * p=0.2, odometry noise N(0, 0.02 m / 0.01 rad), up to 3 closures per pose to earlier
+ * poses (|i-j| >= 5) within 1.5 m, thinned to about edges_per_pose * N edges in total,
+ * initial poses = dead-reckoned odometry, plus round(outlier_frac * #closures) bogus
+ * loops with R4 semantics (uniform random endpoints, zero measurement).
+ * PRNG: splitmix64(seed).                                                         */
 int pgo_synth_manhattan(int32_t n_poses, double edges_per_pose, double outlier_frac,
                         uint64_t seed, pgo_graph** out);                   /* [host] */
 

@@ -161,7 +161,6 @@ class GlibcRand:
         for i in range(1, 31):
             # 16807 * r[i-1] % 2147483647 computed with Schrage's trick on signed 32-bit words
             word = r[i - 1] if r[i - 1] < 2 ** 31 else r[i - 1] - 2 ** 32
-            hi, lo = int(word / 127773), 0
             hi = word // 127773 if word >= 0 else -((-word) // 127773)
             lo = word - hi * 127773
             word = 16807 * lo - 2836 * hi

@@ -22,7 +22,6 @@
 namespace pgo {
 
 static thread_local std::string g_last_error;
-void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(int status, const std::string& msg) {
   g_last_error = msg;
   return status;

@@ -943,9 +943,6 @@ __global__ __launch_bounds__(WG) void k_xnorm(int n_loc, int lo, const double* _
   if (threadIdx.x == 0) part[blockIdx.x] = s2;
 }
 
-__global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
-}
 
 }  // namespace dev
 }  // namespace pgo

@@ -10,7 +10,6 @@
 namespace pgo {
 
 // thread-local detail text behind pgo_last_error()
-void set_error(const std::string& msg);
 int fail(int status, const std::string& msg);
 
 // ---------------------------------------------------------------- host graph

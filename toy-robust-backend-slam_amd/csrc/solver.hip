@@ -273,7 +273,7 @@ struct pgo_handle {
 
   int create(int32_t N, const double* poses_h, int32_t E, const int32_t* ia, const int32_t* ib, const double* meas,
              const uint8_t* kind);
-  int linearize(bool first);
+  int linearize(bool reuse_records);
   int lm_begin();
   int lm_iteration(bool* stop);
   int pcg(int* iters, double* rel);
@@ -547,7 +547,6 @@ int pgo_handle::lm_iteration(bool* stop) {
   pgo_iter_record R;
   memset(&R, 0, sizeof R);
   R.iter = iter;
-  const bool multi = multi_rank();
 
   // LM diagonal + preconditioner, then the linear solve
   double t0 = wall_s();
@@ -592,7 +591,6 @@ int pgo_handle::lm_iteration(bool* stop) {
   t_lin += wall_s() - t0;
   const double ydotg = h_scal[0], yHy = h_scal[1], step2 = h_scal[2];
   const double model = ydotg - 0.5 * yHy;
-  (void)multi;
   if (!std::isfinite(model) || !std::isfinite(step2) || !(model > 0.0)) {  // invalid step
     if (++invalid_run >= 5) {
       termination = PGO_TERM_FAILURE;
