@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--pcg-rtol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=500)
     ap.add_argument("--pcg-block-poses", type=int, default=4, help="poses per block-Jacobi block (GPU and CPU baseline)")
+    ap.add_argument("--halo-exchange", type=int, default=1, help="N > 1: 1 = point-to-point halo exchange of the search direction, 0 = all-gather")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--cpu-iters", type=int, default=4, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
@@ -84,7 +85,7 @@ def main():
     t_gen = time.time() - t_gen
     K, W = args.steps, args.warmup
     opt = P.Options(method=1, max_iters=W + K, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0, pcg_rtol=args.pcg_rtol,
-                    pcg_max_iters=args.pcg_max_iters, pcg_block_poses=args.pcg_block_poses,
+                    pcg_max_iters=args.pcg_max_iters, pcg_block_poses=args.pcg_block_poses, halo_exchange=args.halo_exchange,
                     pcg_check_every=min(100, max(1, args.pcg_max_iters)), verbose=args.verbose if rank == 0 else 0)
     t_create = time.time()
     s = P.Solver(g, opt, comm, device=local_rank)
@@ -137,7 +138,7 @@ def main():
                             % (g.n_poses, n_edges, g.n_edges_of_kind(0), g.n_edges_of_kind(1), g.n_edges_of_kind(2),
                                args.pcg_block_poses, args.pcg_rtol, args.pcg_max_iters),
                 "baseline_config": "configs[4] (synthetic 1M poses / ~4M edges, 10% outliers, sharded PCG)",
-                "parallelism": "pose-id range shards x%d" % world,
+                "parallelism": "pose-id range shards x%d%s" % (world, "" if world == 1 else (", halo exchange" if args.halo_exchange else ", all-gather")),
                 "seed": 20260410,
             },
             "edges_per_sec": n_edges / (k1_ms * 1e-3),

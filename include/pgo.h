@@ -145,7 +145,11 @@ typedef struct pgo_options {
                                   2..32 = dense (3B x 3B) blocks of B consecutive poses (explicit inverses);
                                   0 = auto (32 for graphs of <= 8192 poses, which are launch-latency bound and
                                   chain-like, else 4) */
-  int32_t reserved[7];
+  int32_t halo_exchange;       /* world > 1: how the search direction reaches the other ranks each PCG iteration.
+                                  0 (default) = in-place all-gather of all 3N doubles;
+                                  1 = point-to-point halo exchange: every rank sends each peer only the rows that
+                                      peer's off-diagonal blocks reference (ncclSend/ncclRecv group)            */
+  int32_t reserved[6];
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */

@@ -59,11 +59,13 @@ def test_sharded_tight_solve_intel(tmp_path, world):
     assert np.abs(poses[0] - ref_poses[0]).max() < 1e-7
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_inexact_solve_synthetic(tmp_path, world):
+@pytest.mark.parametrize("world,halo", [(2, 0), (4, 0), (2, 1), (3, 1), (4, 1)])
+def test_sharded_inexact_solve_synthetic(tmp_path, world, halo):
+    """halo = 0: all-gather of the search direction; halo = 1: point-to-point exchange of the referenced rows"""
     cfg = dict(graph="synth", n_poses=20001, seed=9, options=dict(method=1, max_iters=4, pcg_rtol=0.1, pcg_max_iters=300))
     ref, ref_poses = run(1, cfg, tmp_path)
-    res, poses = run(world, cfg, tmp_path)
+    cfg = dict(cfg, options=dict(cfg["options"], halo_exchange=halo))
+    res, poses = run(world, cfg, tmp_path, tag="h%d" % halo)
     for r in range(world):
         np.testing.assert_array_equal(poses[r], poses[0])
         for a, b in zip(res[r]["records"], ref[0]["records"]):

@@ -58,7 +58,7 @@ class Options(C.Structure):
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
                 ("max_lm_diagonal", C.c_double), ("pcg_rtol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("pcg_check_every", C.c_int32), ("verbose", C.c_int32),
-                ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("reserved", C.c_int32 * 6)]
 
     def __init__(self, **kw):
         super().__init__()

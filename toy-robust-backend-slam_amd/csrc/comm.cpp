@@ -42,6 +42,20 @@ struct RcclComm final : pgo_comm {
     if (r != ncclSuccess) return fail(PGO_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r));
     return PGO_OK;
   }
+  int exchange(const double* sendbuf, const int64_t* send_off, double* recvbuf, const int64_t* recv_off,
+               hipStream_t s) override {
+    ncclResult_t r = ncclGroupStart();
+    for (int peer = 0; peer < world && r == ncclSuccess; ++peer) {
+      if (peer == rank) continue;
+      const int64_t ns = send_off[peer + 1] - send_off[peer], nr = recv_off[peer + 1] - recv_off[peer];
+      if (ns > 0) r = ncclSend(sendbuf + send_off[peer], (size_t)ns, ncclDouble, peer, comm, s);
+      if (nr > 0 && r == ncclSuccess) r = ncclRecv(recvbuf + recv_off[peer], (size_t)nr, ncclDouble, peer, comm, s);
+    }
+    ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess)
+      return fail(PGO_ERR_COMM, std::string("ncclSend/ncclRecv group: ") + ncclGetErrorString(r != ncclSuccess ? r : r2));
+    return PGO_OK;
+  }
 };
 
 // ------------------------------------------------------------------- shm
@@ -123,6 +137,29 @@ struct ShmComm final : pgo_comm {
       if (st) return st;
     }
     return PGO_OK;
+  }
+  int exchange(const double* sendbuf, const int64_t* send_off, double* recvbuf, const int64_t* recv_off,
+               hipStream_t s) override {
+    // slot layout: [world + 1 offsets (int64)] [all outgoing segments]
+    const int64_t hdr_bytes = (int64_t)(world + 1) * 8, total = send_off[world];
+    if (hdr_bytes + total * 8 > slot_bytes) return fail(PGO_ERR_COMM, "shm exchange larger than a slot");
+    memcpy(slot(rank), send_off, (size_t)hdr_bytes);
+    if (total > 0 && (hipMemcpyAsync(slot(rank) + hdr_bytes, sendbuf, (size_t)total * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                      hipStreamSynchronize(s) != hipSuccess))
+      return fail(PGO_ERR_HIP, "shm exchange D2H");
+    int st = barrier();
+    if (st) return st;
+    for (int peer = 0; peer < world; ++peer) {
+      if (peer == rank) continue;
+      const int64_t* poff = (const int64_t*)slot(peer);
+      const int64_t n = poff[rank + 1] - poff[rank];
+      if (n != recv_off[peer + 1] - recv_off[peer]) return fail(PGO_ERR_COMM, "shm exchange: send/recv counts disagree");
+      if (n > 0 && hipMemcpyAsync(recvbuf + recv_off[peer], slot(peer) + hdr_bytes + poff[rank] * 8, (size_t)n * 8,
+                                  hipMemcpyHostToDevice, s) != hipSuccess)
+        return fail(PGO_ERR_HIP, "shm exchange H2D");
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(PGO_ERR_HIP, "shm exchange sync");
+    return barrier();
   }
 };
 

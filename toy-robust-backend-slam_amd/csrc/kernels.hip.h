@@ -915,6 +915,22 @@ __global__ void k_scatter_owned(int n_loc, int lo, const double* __restrict__ sr
   }
 }
 
+// halo exchange helpers: pack rows of the gather vector into a contiguous buffer / scatter them back
+__global__ void k_pack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
+                            double* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i / 3;
+    dst[i] = src[PS * (int64_t)rows[k] + (i - 3 * k)];
+  }
+}
+__global__ void k_unpack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
+                              double* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i / 3;
+    dst[PS * (int64_t)rows[k] + (i - 3 * k)] = src[i];
+  }
+}
+
 // candidate = x - S y on the owned rows; partials of |step|^2
 __global__ __launch_bounds__(WG) void k_candidate(int n_loc, int lo, const double* __restrict__ x,
                                                   const double* __restrict__ scale, const double* __restrict__ y,

@@ -61,6 +61,12 @@ struct ShardStructure {
   // incidences forms a tile of its own and is processed in chunks)
   std::vector<int32_t> tile_row;        // n_tiles + 1, LOCAL row index
   int32_t n_tiles() const { return (int32_t)tile_row.size() - 1; }
+
+  // halo of the search direction (world > 1): rows of other ranks that this rank's off-diagonal blocks
+  // reference (recv), and rows of this rank that other ranks reference (send); both grouped by peer and
+  // sorted by global row, so that peer s's send list to r is exactly r's recv list from s.
+  std::vector<int32_t> halo_send_row, halo_recv_row;   // global rows
+  std::vector<int64_t> halo_send_off, halo_recv_off;   // world + 1 each, in rows
 };
 
 constexpr int TILE_INC = 256;

@@ -88,6 +88,11 @@ struct pgo_handle {
   size_t grp_lds = 0;
   int grp_prep_grid = 1;
   double* ginv = nullptr;
+  // halo exchange of the search direction (world > 1, opt.halo_exchange)
+  bool use_halo = false;
+  int32_t *halo_send_rows = nullptr, *halo_recv_rows = nullptr;
+  double *halo_send_buf = nullptr, *halo_recv_buf = nullptr;
+  std::vector<int64_t> halo_send_off3, halo_recv_off3;  // offsets in doubles (3 per row)
   // captured slice of PCG iterations (world == 1)
   hipGraphExec_t cg_graph_exec = nullptr;
   int cg_graph_len = 0;
@@ -168,6 +173,25 @@ struct pgo_handle {
   }
   int allgather(double* full, int stride = 3) {
     if (multi_rank()) PGOC(comm->allgather_inplace(full, (int64_t)stride * S.rows_per_rank, stream));
+    return PGO_OK;
+  }
+  // make the owned rows of the gather vector visible where the peers need them: either everything
+  // (all-gather) or only the rows their off-diagonal blocks reference (halo exchange)
+  int share_gather_vector(double* full) {
+    if (!multi_rank()) return PGO_OK;
+    if (!use_halo) return allgather(full, dev::PS);
+    const int64_t ns = (int64_t)S.halo_send_row.size(), nr = (int64_t)S.halo_recv_row.size();
+    if (ns > 0) {
+      hipLaunchKernelGGL(dev::k_pack_rows, dim3((unsigned)std::min<int64_t>((3 * ns + 255) / 256, 2048)), dim3(256), 0, stream, ns,
+                         (const int32_t*)halo_send_rows, (const double*)full, halo_send_buf);
+      PGOC(check_launch("k_pack_rows"));
+    }
+    PGOC(comm->exchange(halo_send_buf, halo_send_off3.data(), halo_recv_buf, halo_recv_off3.data(), stream));
+    if (nr > 0) {
+      hipLaunchKernelGGL(dev::k_unpack_rows, dim3((unsigned)std::min<int64_t>((3 * nr + 255) / 256, 2048)), dim3(256), 0, stream, nr,
+                         (const int32_t*)halo_recv_rows, (const double*)halo_recv_buf, full);
+      PGOC(check_launch("k_unpack_rows"));
+    }
     return PGO_OK;
   }
 
@@ -347,6 +371,22 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(upload(inc_edge, S.inc_edge));
   PGOC(upload(inc_col, S.inc_col));
   PGOC(upload(tile_row, S.tile_row));
+  // halo lists for the point-to-point exchange of the search direction
+  use_halo = world > 1 && opt.halo_exchange != 0;
+  if (use_halo) {
+    PGOC(dalloc(&halo_send_rows, (int64_t)S.halo_send_row.size()));
+    PGOC(dalloc(&halo_recv_rows, (int64_t)S.halo_recv_row.size()));
+    PGOC(dalloc(&halo_send_buf, 3 * (int64_t)S.halo_send_row.size()));
+    PGOC(dalloc(&halo_recv_buf, 3 * (int64_t)S.halo_recv_row.size()));
+    PGOC(upload(halo_send_rows, S.halo_send_row));
+    PGOC(upload(halo_recv_rows, S.halo_recv_row));
+    halo_send_off3.resize(S.halo_send_off.size());
+    halo_recv_off3.resize(S.halo_recv_off.size());
+    for (size_t k = 0; k < S.halo_send_off.size(); ++k) {
+      halo_send_off3[k] = 3 * S.halo_send_off[k];
+      halo_recv_off3[k] = 3 * S.halo_recv_off[k];
+    }
+  }
   // preconditioner block size
   if (grp_B > 1 && NL > 0) {
     grp_nb = 3 * grp_B;
@@ -460,7 +500,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
   PGOC(reduce_to_scal({{part[0], g_u1, 0}, {part[1], g_u1, 0}}, 4));
   hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
   PGOC(check_launch("k_cg_init_fin"));
-  PGOC(allgather(p_full, dev::PS));
+  PGOC(share_gather_vector(p_full));
   const int max_it = std::max(0, opt.pcg_max_iters);
   int every = std::max(1, opt.pcg_check_every);
   // one PCG iteration = 3 dependent launches; `par` is the r.z double-buffer parity baked into the arguments
@@ -476,7 +516,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
       PGOC(reduce_to_scal({{part[1], g_u1, 0}, {part[2], g_u1, 0}}, 7));
       hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
       PGOC(check_launch("k_cg_update2"));
-      PGOC(allgather(p_full, dev::PS));
+      PGOC(share_gather_vector(p_full));
     } else {
       hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_u1, part[2], g_u1);
       PGOC(check_launch("k_cg_update2"));
@@ -578,7 +618,7 @@ int pgo_handle::lm_iteration(bool* stop) {
   // model_cost_change = -(J d).(r + J d / 2), d = -S y   ==   y.gs - y.(H y) / 2
   hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
   PGOC(check_launch("k_scatter_owned"));
-  PGOC(allgather(p_full, dev::PS));
+  PGOC(share_gather_vector(p_full));
   PGOC(spmv_enqueue(p_full, ap, part[0], 0, nullptr));  // part[0] <- partials of y.(H y)
   hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs, part[1]);
   PGOC(check_launch("k_dot"));

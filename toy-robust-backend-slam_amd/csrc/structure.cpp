@@ -121,6 +121,38 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
     }
   }
 
+  // halo lists (need the WHOLE edge list: what the peers reference of this rank's rows)
+  S->halo_send_off.assign((size_t)world + 1, 0);
+  S->halo_recv_off.assign((size_t)world + 1, 0);
+  S->halo_send_row.clear();
+  S->halo_recv_row.clear();
+  if (world > 1) {
+    const int32_t rpr = S->rows_per_rank;
+    std::vector<std::vector<int32_t>> snd(world), rcv(world);
+    for (int32_t e = 0; e < E; ++e) {
+      const int oa = ia[e] / rpr, ob = ib[e] / rpr;
+      if (oa == ob) continue;
+      if (oa == rank) {
+        snd[ob].push_back(ia[e]);  // peer ob's row ib[e] has a block in column ia[e]
+        rcv[ob].push_back(ib[e]);
+      }
+      if (ob == rank) {
+        snd[oa].push_back(ib[e]);
+        rcv[oa].push_back(ia[e]);
+      }
+    }
+    for (int s = 0; s < world; ++s) {
+      for (auto* v : {&snd[s], &rcv[s]}) {
+        std::sort(v->begin(), v->end());
+        v->erase(std::unique(v->begin(), v->end()), v->end());
+      }
+      S->halo_send_row.insert(S->halo_send_row.end(), snd[s].begin(), snd[s].end());
+      S->halo_recv_row.insert(S->halo_recv_row.end(), rcv[s].begin(), rcv[s].end());
+      S->halo_send_off[s + 1] = (int64_t)S->halo_send_row.size();
+      S->halo_recv_off[s + 1] = (int64_t)S->halo_recv_row.size();
+    }
+  }
+
   // tiles
   S->tile_row.clear();
   S->tile_row.push_back(0);
