@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=4, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
     ap.add_argument("--verbose", type=int, default=0)
+    ap.add_argument("--comm", choices=["rccl", "shm"], default="rccl",
+                    help="shm = rehearsal on ONE GPU: gloo process group + host-staged shared-memory communicator, all ranks on cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -60,6 +62,9 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP backend has no CPU path", file=sys.stderr)
         sys.exit(3)
+    rehearsal = args.comm == "shm"
+    if rehearsal:
+        local_rank = 0  # every rank shares cuda:0 (RCCL would refuse duplicate devices)
     torch.cuda.set_device(local_rank)
     dist = None
     comm = None
@@ -68,12 +73,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(P.Comm.unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        comm = P.Comm.rccl(bytes(uid.cpu().numpy().tobytes()), rank, world, local_rank)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            comm = P.Comm.shm("pgo_bench_%s" % os.environ["MASTER_PORT"], rank, world, 0)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(P.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            comm = P.Comm.rccl(bytes(uid.cpu().numpy().tobytes()), rank, world, local_rank)
 
     def barrier():
         if dist is not None:
@@ -109,7 +118,8 @@ def main():
     k1c = s.bench_eval(reps, False)
     k2 = s.bench_assemble(reps)
     k3 = s.bench_spmv(reps)
-    vals = torch.tensor([dt, k1.ms_avg, k1c.ms_avg, k2.ms_avg, k3.ms_avg], dtype=torch.float64, device="cuda")
+    vals = torch.tensor([dt, k1.ms_avg, k1c.ms_avg, k2.ms_avg, k3.ms_avg], dtype=torch.float64,
+                        device="cpu" if rehearsal else "cuda")
     if dist is not None:
         dist.all_reduce(vals, op=dist.ReduceOp.MAX)
     dt_max, k1_ms, k1c_ms, k2_ms, k3_ms = [float(v) for v in vals.cpu()]
