@@ -264,6 +264,10 @@ int pgo_debug_normal_eq(pgo_t* h, double* g_or_null, double* hdiag_or_null);    
 int pgo_shard_plan(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
                    int world, int rank, int row_align, int32_t* lo, int32_t* hi,
                    int32_t* n_local_edges, int32_t* n_cut_edges);                 /* [host] */
+/* halo of that plan: send_rows[s] = how many of rank's rows peer s references, recv_rows[s] = how many of
+ * peer s's rows rank references (arrays of `world` entries; the own-rank entries are 0).  Pure host logic.  */
+int pgo_shard_halo(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
+                   int world, int rank, int row_align, int64_t* send_rows, int64_t* recv_rows); /* [host] */
 
 #ifdef __cplusplus
 }

@@ -2,9 +2,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import toy_robust_backend_slam_amd as P
-for n in (10000, 100000, 1000000):
+for n in (1000000,):
     g = P.synth_manhattan(n, 4.0, 0.10, 20260410)
-    for B in (1, 4, 8):
+    for B in (3, 4, 5, 6):
         s = P.Solver(g, P.Options(method=1, max_iters=10, ftol=0.0, gtol=0.0, ptol=0.0, pcg_rtol=0.1, pcg_max_iters=500, pcg_check_every=50, pcg_block_poses=B))
         s.solve(); s.set_poses(np.array(g.poses))
         t = time.perf_counter(); summ = s.solve(); dt = time.perf_counter() - t

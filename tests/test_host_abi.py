@@ -173,6 +173,28 @@ def test_shard_plan(pgo, world):
         assert sum(b - a for a, b, _, _ in (pgo.shard_plan(N, ia, ib, world, r, align) for r in range(world))) == N
 
 
+@pytest.mark.parametrize("world,align", [(2, 1), (3, 4), (8, 4)])
+def test_shard_halo_plan(pgo, world, align):
+    """halo exchange plan vs numpy: rank r receives from s the distinct columns (owned by s) of r's rows, and what
+    r sends to s is what s receives from r"""
+    g = pgo.synth_manhattan(10001, 4.0, 0.10, 3)
+    ia, ib = np.array(g.ia), np.array(g.ib)
+    N = g.n_poses
+    rpr = -(-(-(-N // world)) // align) * align
+    owner_a, owner_b = ia // rpr, ib // rpr
+    plans = [pgo.shard_halo(N, ia, ib, world, r, align) for r in range(world)]
+    for r in range(world):
+        snd, rcv = plans[r]
+        assert snd[r] == 0 and rcv[r] == 0
+        for s_ in range(world):
+            if s_ == r:
+                continue
+            need = np.unique(np.concatenate([ib[(owner_a == r) & (owner_b == s_)], ia[(owner_b == r) & (owner_a == s_)]]))
+            assert rcv[s_] == len(need)
+            assert plans[s_][0][r] == rcv[s_]  # peer's send count == my receive count
+    assert pgo.shard_halo(N, ia, ib, 1, 0)[0].sum() == 0
+
+
 # ------------------------------------------------------------------- C-ABI
 def test_library_exports_every_declared_symbol(pgo):
     hdr = open(os.path.join(ROOT, "include", "pgo.h")).read()

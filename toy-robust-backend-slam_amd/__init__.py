@@ -21,7 +21,7 @@ import numpy as np
 from . import _build
 
 __all__ = ["PgoError", "Options", "Summary", "IterRecord", "ReadG2O", "Graph", "Solver", "Comm", "lib", "build",
-           "synth_manhattan", "shard_plan", "KernelStats", "EXPORTS", "TERMINATION"]
+           "synth_manhattan", "shard_plan", "shard_halo", "KernelStats", "EXPORTS", "TERMINATION"]
 
 EDGE_ODOMETRY, EDGE_CLOSURE, EDGE_BOGUS = 0, 1, 2
 TERMINATION = {1: "CONVERGENCE_FTOL", 2: "CONVERGENCE_GTOL", 3: "CONVERGENCE_PTOL", 4: "NO_CONVERGENCE",
@@ -39,7 +39,7 @@ EXPORTS = [
     "pgo_create", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_solve", "pgo_lm_begin", "pgo_lm_step",
     "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses",
     "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_debug_spmv", "pgo_debug_normal_eq",
-    "pgo_shard_plan",
+    "pgo_shard_plan", "pgo_shard_halo",
 ]
 
 
@@ -166,6 +166,8 @@ def lib():
     L.pgo_debug_spmv.argtypes = [vp, dp, dp]
     L.pgo_debug_normal_eq.argtypes = [vp, dp, dp]
     L.pgo_shard_plan.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
+    L.pgo_shard_halo.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int64)]
     _LIB = L
     return L
 
@@ -318,6 +320,16 @@ def shard_plan(n_poses, ia, ib, world, rank, row_align=1):
     _check(lib().pgo_shard_plan(n_poses, len(ia), _ip(ia), _ip(ib), world, rank, row_align, C.byref(lo), C.byref(hi),
                                 C.byref(nl), C.byref(nc)))
     return lo.value, hi.value, nl.value, nc.value
+
+
+def shard_halo(n_poses, ia, ib, world, rank, row_align=1):
+    """(send_rows[world], recv_rows[world]) of the point-to-point halo exchange plan"""
+    ia = np.ascontiguousarray(ia, np.int32)
+    ib = np.ascontiguousarray(ib, np.int32)
+    snd, rcv = np.zeros(world, np.int64), np.zeros(world, np.int64)
+    _check(lib().pgo_shard_halo(n_poses, len(ia), _ip(ia), _ip(ib), world, rank, row_align,
+                                snd.ctypes.data_as(C.POINTER(C.c_int64)), rcv.ctypes.data_as(C.POINTER(C.c_int64))))
+    return snd, rcv
 
 
 class Comm:

@@ -17,6 +17,42 @@
 
 namespace pgo {
 
+// Halo of the gather vector for world > 1 (needs the WHOLE edge list: what the peers reference of this
+// rank's rows).  Both lists are grouped by peer and sorted by global row, so that rank s's send list to r is
+// exactly r's receive list from s.
+static void build_halo_lists(int32_t E, const int32_t* ia, const int32_t* ib, ShardStructure* S) {
+  const int world = S->world, rank = S->rank;
+  S->halo_send_off.assign((size_t)world + 1, 0);
+  S->halo_recv_off.assign((size_t)world + 1, 0);
+  S->halo_send_row.clear();
+  S->halo_recv_row.clear();
+  if (world <= 1) return;
+  const int32_t rpr = S->rows_per_rank;
+  std::vector<std::vector<int32_t>> snd(world), rcv(world);
+  for (int32_t e = 0; e < E; ++e) {
+    const int oa = ia[e] / rpr, ob = ib[e] / rpr;
+    if (oa == ob) continue;
+    if (oa == rank) {
+      snd[ob].push_back(ia[e]);  // peer ob's row ib[e] has a block in column ia[e]
+      rcv[ob].push_back(ib[e]);
+    }
+    if (ob == rank) {
+      snd[oa].push_back(ib[e]);
+      rcv[oa].push_back(ia[e]);
+    }
+  }
+  for (int s = 0; s < world; ++s) {
+    for (auto* v : {&snd[s], &rcv[s]}) {
+      std::sort(v->begin(), v->end());
+      v->erase(std::unique(v->begin(), v->end()), v->end());
+    }
+    S->halo_send_row.insert(S->halo_send_row.end(), snd[s].begin(), snd[s].end());
+    S->halo_recv_row.insert(S->halo_recv_row.end(), rcv[s].begin(), rcv[s].end());
+    S->halo_send_off[s + 1] = (int64_t)S->halo_send_row.size();
+    S->halo_recv_off[s + 1] = (int64_t)S->halo_recv_row.size();
+  }
+}
+
 int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t* ib, const double* meas,
                           const uint8_t* kind, int method, int world, int rank, int row_align, ShardStructure* S) {
   if (N <= 0 || E < 0 || world < 1 || rank < 0 || rank >= world || row_align < 1)
@@ -121,37 +157,7 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
     }
   }
 
-  // halo lists (need the WHOLE edge list: what the peers reference of this rank's rows)
-  S->halo_send_off.assign((size_t)world + 1, 0);
-  S->halo_recv_off.assign((size_t)world + 1, 0);
-  S->halo_send_row.clear();
-  S->halo_recv_row.clear();
-  if (world > 1) {
-    const int32_t rpr = S->rows_per_rank;
-    std::vector<std::vector<int32_t>> snd(world), rcv(world);
-    for (int32_t e = 0; e < E; ++e) {
-      const int oa = ia[e] / rpr, ob = ib[e] / rpr;
-      if (oa == ob) continue;
-      if (oa == rank) {
-        snd[ob].push_back(ia[e]);  // peer ob's row ib[e] has a block in column ia[e]
-        rcv[ob].push_back(ib[e]);
-      }
-      if (ob == rank) {
-        snd[oa].push_back(ib[e]);
-        rcv[oa].push_back(ia[e]);
-      }
-    }
-    for (int s = 0; s < world; ++s) {
-      for (auto* v : {&snd[s], &rcv[s]}) {
-        std::sort(v->begin(), v->end());
-        v->erase(std::unique(v->begin(), v->end()), v->end());
-      }
-      S->halo_send_row.insert(S->halo_send_row.end(), snd[s].begin(), snd[s].end());
-      S->halo_recv_row.insert(S->halo_recv_row.end(), rcv[s].begin(), rcv[s].end());
-      S->halo_send_off[s + 1] = (int64_t)S->halo_send_row.size();
-      S->halo_recv_off[s + 1] = (int64_t)S->halo_recv_row.size();
-    }
-  }
+  build_halo_lists(E, ia, ib, S);
 
   // tiles
   S->tile_row.clear();
@@ -190,5 +196,26 @@ extern "C" int pgo_shard_plan(int32_t n_poses, int32_t n_edges, const int32_t* i
   if (hi) *hi = (int32_t)h;
   if (n_local_edges) *n_local_edges = nl;
   if (n_cut_edges) *n_cut_edges = nc;
+  return PGO_OK;
+}
+
+extern "C" int pgo_shard_halo(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int world, int rank,
+                              int row_align, int64_t* send_rows, int64_t* recv_rows) {
+  if (n_poses <= 0 || n_edges < 0 || world < 1 || rank < 0 || rank >= world || row_align < 1 || (n_edges && (!ia || !ib)) ||
+      !send_rows || !recv_rows)
+    return pgo::fail(PGO_ERR_INVALID_ARG, "pgo_shard_halo: bad argument");
+  for (int32_t e = 0; e < n_edges; ++e)
+    if (ia[e] < 0 || ia[e] >= n_poses || ib[e] < 0 || ib[e] >= n_poses)
+      return pgo::fail(PGO_ERR_INVALID_ARG, "pgo_shard_halo: endpoint out of range");
+  pgo::ShardStructure S;
+  S.n_poses = n_poses;
+  S.world = world;
+  S.rank = rank;
+  S.rows_per_rank = pgo::rows_per_rank(n_poses, world, row_align);
+  pgo::build_halo_lists(n_edges, ia, ib, &S);
+  for (int s = 0; s < world; ++s) {
+    send_rows[s] = S.halo_send_off[s + 1] - S.halo_send_off[s];
+    recv_rows[s] = S.halo_recv_off[s + 1] - S.halo_recv_off[s];
+  }
   return PGO_OK;
 }
