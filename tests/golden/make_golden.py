@@ -55,7 +55,7 @@ def main():
 
     # LM traces + final poses (direct solve) for the BASELINE configs C1..C3
     cases = [("INTEL", 50, 1), ("INTEL", 50, 0), ("INTEL", 0, 1), ("MIT", 0, 1), ("MIT", 0, 0), ("M3500", 0, 1),
-             ("M3500", 0, 0), ("CSAIL", 0, 1)]
+             ("M3500", 0, 0), ("CSAIL", 0, 1), ("FR079", 0, 1), ("FRH", 0, 1), ("FRH", 20, 1)]
     for name, n_out, method in cases:
         gg = O.read_g2o(os.path.join(DATA, name + ".g2o"))
         if n_out:

@@ -197,7 +197,7 @@ def test_heavy_row_duplicates_isolated(pgo, oracle, n_leaves):
 
 # ----------------------------------------------------------------- LM solve
 CASES = [("INTEL", 50, 1), ("INTEL", 50, 0), ("INTEL", 0, 1), ("MIT", 0, 1), ("MIT", 0, 0), ("M3500", 0, 1),
-         ("M3500", 0, 0), ("CSAIL", 0, 1)]
+         ("M3500", 0, 0), ("CSAIL", 0, 1), ("FR079", 0, 1), ("FRH", 0, 1), ("FRH", 20, 1)]
 
 
 @pytest.mark.parametrize("name,n_out,method", CASES)
