@@ -253,7 +253,8 @@ struct AsmArgs {
 };
 
 // One workgroup per tile of rows.  Phase A: one lane per incidence reads the
-// 176-byte edge record (11 x 16-byte loads), forms the off-diagonal block (stored
+// 112-byte edge record (7 x 16-byte loads), expands the implied second block, applies the Jacobi column
+// scales of both endpoints, forms the off-diagonal block (stored
 // straight to its plane slot, coalesced) and its diagonal/gradient contribution
 // (9 doubles, staged in LDS).  Phase B: one thread per (row, component) sums its
 // row's staged contributions in incidence order -- a fixed order, so the result is

@@ -7,7 +7,7 @@
 //   `row_align` (the preconditioner's pose-block size: shard boundaries then coincide with block
 //   boundaries, so the preconditioner -- and with it the PCG iterates -- do not depend on the world size).
 //   A rank evaluates EVERY edge touching one of its rows (cut edges are evaluated
-//   on both owners - 85 bytes of input per edge - instead of exchanging 176-byte
+//   on both owners - 81 bytes of input per edge - instead of exchanging 112-byte
 //   Jacobian records), so assembly needs no communication at all.  An edge's cost
 //   is counted on the rank that owns its first endpoint Edge::a.
 #include <algorithm>
