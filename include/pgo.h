@@ -3,7 +3,8 @@
  *
  * This is the drop-in boundary for ONE path of wei-ght/toy-robust-backend-slam:
  * DCS-ceres/main.cpp METHOD 0/1 (SE(2) odometry + loop-closure least squares,
- * Dynamic Covariance Scaling, HuberLoss(0.01), Ceres LM).  Everything the
+ * Dynamic Covariance Scaling, HuberLoss(0.01), Ceres LM) and, since SURVEY.md section 8(f) ranks it
+ * next, METHOD 2 (switchable constraints).  Everything the
  * reference does between `ceres::Problem problem;` (main.cpp:66) and the end of
  * `ceres::Solve` (main.cpp:163) is replaced by pgo_create / pgo_solve /
  * pgo_get_poses; the g2o loader, classifier, outlier injector and writers
@@ -41,7 +42,7 @@ typedef enum pgo_status {
   PGO_ERR_COMM = -6,          /* RCCL / shm communicator failure              */
   PGO_ERR_NUMERIC = -7,       /* non-finite residual/Jacobian at the current point
                                  (Ceres: "Residual and Jacobian evaluation failed") */
-  PGO_ERR_UNSUPPORTED = -8,   /* METHOD 2/3/4 etc.                            */
+  PGO_ERR_UNSUPPORTED = -8,   /* METHOD 3/4 etc.                              */
   PGO_ERR_NOMEM = -9
 } pgo_status;
 
@@ -99,6 +100,9 @@ int pgo_inject_outliers(pgo_graph* g, int32_t count, int64_t seed);        /* [h
  * digits); precision > 0 : that many significant digits (17 round-trips).        */
 int pgo_write_nodes(const pgo_graph* g, const char* path, int precision);  /* [host] */
 int pgo_write_edges(const pgo_graph* g, const char* path);                 /* [host] */
+/* writePoseGraph_switches (g2o_util.h:114-148): three sections, "<a> <b> <type> <prior> <switch>" per edge;
+ * switches: E values in the graph's edge order (prior is 1.0 everywhere, as main.cpp:119,141)             */
+int pgo_write_switches(const pgo_graph* g, const char* path, const double* switches); /* [host] */
 /* g2o writer (VERTEX_SE2 / EDGE_SE2), for the synthetic configs                  */
 int pgo_write_g2o(const pgo_graph* g, const char* path);                   /* [host] */
 
@@ -119,7 +123,8 @@ int pgo_synth_manhattan(int32_t n_poses, double edges_per_pose, double outlier_f
  * constants hard-coded in the reference: Huber 0.01 (main.cpp:68), phi 0.5
  * (src/ceres_error.cpp:185), fixed pose 0 (main.cpp:153).                        */
 typedef struct pgo_options {
-  int32_t method;              /* 0 = plain (OdometryResidue everywhere), 1 = DCS on closure+bogus (main.cpp:112-114,135-137) */
+  int32_t method;              /* 0 = plain (OdometryResidue everywhere), 1 = DCS on closure+bogus (main.cpp:112-114,135-137),
+                                  2 = switchable constraints on closure+bogus (main.cpp:115-125,138-145) */
   int32_t max_iters;           /* 50   Solver::Options::max_num_iterations        */
   int32_t fixed_pose;          /* 0    position of the constant pose, -1 = none   */
   int32_t jacobi_scaling;      /* 1                                               */
@@ -149,7 +154,8 @@ typedef struct pgo_options {
                                   0 (default) = in-place all-gather of all 3N doubles;
                                   1 = point-to-point halo exchange: every rank sends each peer only the rows that
                                       peer's off-diagonal blocks reference (ncclSend/ncclRecv group)            */
-  int32_t reserved[6];
+  double  sc_prior_lambda;     /* 1.0  METHOD 2: weight of the switch prior sqrt(lambda)(1 - s)  (main.cpp:107)    */
+  int32_t reserved[4];
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */
@@ -237,6 +243,9 @@ int32_t pgo_num_iter_records(const pgo_t* h);
 int pgo_get_iter_records(const pgo_t* h, pgo_iter_record* out, int32_t cap);
 
 int pgo_get_poses(pgo_t* h, double* out_xyt /* N x 3 */);                         /* [gpu] */
+/* METHOD 2: current switch per edge in the caller's edge order (1.0 for odometry edges); optionally also
+ * d e / d s (E x 3, after the Huber corrector) of the latest Jacobian evaluation.  world == 1.             */
+int pgo_get_switches(pgo_t* h, double* switches /* E */, double* js_or_null /* E x 3 */);   /* [gpu] */
 int pgo_set_poses(pgo_t* h, const double* poses_xyt);                             /* [gpu] */
 
 /* ------------------------------------------------ kernel-level entry points

@@ -72,6 +72,9 @@ def lib():
         L.pgo_oracle_eval.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, C.c_int, C.c_double, C.c_double,
                                       C.c_int, dp, dp, C.c_int]
         L.pgo_oracle_eval.restype = C.c_double
+        L.pgo_oracle_eval_sc.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, dp, C.c_double, C.c_double, C.c_int, dp, dp,
+                                         dp, dp, C.c_int]
+        L.pgo_oracle_eval_sc.restype = C.c_double
         L.pgo_oracle_lm_pcg.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, C.POINTER(_Opts), C.POINTER(_Iter),
                                         C.c_int, C.POINTER(C.c_int), C.POINTER(_Summary)]
         L.pgo_oracle_lm_pcg.restype = C.c_int
@@ -237,6 +240,21 @@ def evaluate(g: Graph, poses=None, method: int = 1, phi: float = 0.5, delta: flo
     cost = lib().pgo_oracle_eval(g.n_poses, _dp(poses), E, _ip(ia), _ip(ib), _dp(meas), _bp(kind), method, phi, delta,
                                  int(apply_loss), _dp(r), _dp(J), threads)
     return cost, r, J
+
+
+def evaluate_sc(g: Graph, poses=None, switches=None, lam: float = 1.0, delta: float = 0.01, apply_loss: bool = True,
+                want: bool = True, threads: int = 1):
+    """METHOD 2 residual blocks.  switches: [E] (entries of odometry edges ignored; default all 1).
+    Returns cost, r [E,3], J [E,18], Js [E,3], q [E] (the four arrays are None when want is False)."""
+    poses = np.ascontiguousarray(g.poses if poses is None else poses, np.float64)
+    E = g.n_edges
+    sw = np.ascontiguousarray(np.ones(E) if switches is None else switches, np.float64)
+    r, J, Js, q = (np.zeros((E, 3)), np.zeros((E, 18)), np.zeros((E, 3)), np.zeros(E)) if want else (None, None, None, None)
+    ia, ib = np.ascontiguousarray(g.ia, np.int32), np.ascontiguousarray(g.ib, np.int32)
+    meas, kind = np.ascontiguousarray(g.meas, np.float64), np.ascontiguousarray(g.kind, np.uint8)
+    cost = lib().pgo_oracle_eval_sc(g.n_poses, _dp(poses), E, _ip(ia), _ip(ib), _dp(meas), _bp(kind), _dp(sw), lam, delta,
+                                    int(apply_loss), _dp(r), _dp(J), _dp(Js), _dp(q), threads)
+    return cost, r, J, Js, q
 
 
 def normal_eq(g: Graph, poses=None, method=1, phi=0.5, delta=0.01, fixed_pose=0, s=None, x=None, threads=1):
@@ -465,3 +483,130 @@ def lm_pcg(g: Graph, opt: Options = Options()) -> Result:
     out.seconds = dict(total=summ.seconds_total, eval=summ.seconds_eval, assemble=summ.seconds_assemble,
                        linear=summ.seconds_linear, candidate=summ.seconds_candidate)
     return out
+
+
+def lm_direct_sc(g: Graph, opt: Options = Options(), lam: float = 1.0) -> Result:
+    """METHOD 2 (switchable constraints): the same Ceres policy as lm_direct on the joint parameter vector
+    [poses; one switch per closure/bogus edge (initialised to 1.0)], residual blocks as in pgo_oracle_eval_sc,
+    sparse direct solve.  Result.switches holds the final switch per edge (1.0 for odometry edges)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    N, E = g.n_poses, g.n_edges
+    sc = np.nonzero(g.kind != 0)[0]
+    M = len(sc)
+    sw_col = -np.ones(E, np.int64)
+    sw_col[sc] = 3 * N + np.arange(M)
+    z = np.concatenate([np.array(g.poses, np.float64).reshape(-1), np.ones(M)])
+    free = np.ones(3 * N + M, bool)
+    if opt.fixed_pose >= 0:
+        free[3 * opt.fixed_pose:3 * opt.fixed_pose + 3] = False
+    free_idx = np.nonzero(free)[0]
+    rows_p = np.repeat(np.arange(3 * E).reshape(E, 3), 6, axis=1).reshape(-1)
+    cols_p = np.concatenate([3 * g.ia[:, None] + np.arange(3), 3 * g.ib[:, None] + np.arange(3)], axis=1)
+    cols_p = np.tile(cols_p, (1, 3)).reshape(-1).astype(np.int64)
+    rows_s = (3 * sc[:, None] + np.arange(3)).reshape(-1)
+    cols_s = np.repeat(sw_col[sc], 3)
+    rows_q = 3 * E + np.arange(M)
+    sl = np.sqrt(lam)
+
+    def ev(zv, with_j):
+        sw = np.ones(E)
+        sw[sc] = zv[3 * N:]
+        cost, r, J, Js, q = evaluate_sc(g, zv[:3 * N].reshape(N, 3), sw, lam, opt.huber_delta, True, with_j, opt.threads)
+        if not with_j:
+            return cost, None, None
+        A = sp.csr_matrix((np.concatenate([J.reshape(-1), Js[sc].reshape(-1), np.full(M, -sl)]),
+                           (np.concatenate([rows_p, rows_s, rows_q]), np.concatenate([cols_p, cols_s, sw_col[sc]]))),
+                          shape=(3 * E + M, 3 * N + M))
+        return cost, np.concatenate([r.reshape(-1), q[sc]]), A[:, free_idx].tocsc()
+
+    cost, rvec, A = ev(z, True)
+    res = Result(z[:3 * N].reshape(N, 3), 4, 0, 0, cost, cost)
+    if not np.isfinite(cost):
+        res.termination = 6
+        return res
+    s = 1.0 / (1.0 + np.sqrt(np.asarray(A.multiply(A).sum(axis=0)).reshape(-1))) if opt.jacobi_scaling else np.ones(A.shape[1])
+    grad = A.T @ rvec
+    gmax = float(np.max(np.abs(grad)))
+    x_norm = float(np.linalg.norm(z[free_idx]))
+    radius, dec, prev_success, invalid_run = opt.radius0, 2.0, True, 0
+    recs = [dict(iter=0, step_ok=1, cost=cost, cost_change=0.0, gradient_max_norm=gmax, step_norm=0.0,
+                 relative_decrease=0.0, radius=radius)]
+    it, term = 0, 4
+    while True:
+        it += 1
+        if it > opt.max_iters:
+            term, it = 4, it - 1
+            break
+        if prev_success and gmax <= opt.gtol:
+            term, it = 2, it - 1
+            break
+        if radius < opt.min_radius:
+            term, it = 5, it - 1
+            break
+        As = A @ sp.diags(s)
+        H = (As.T @ As).tocsc()
+        D2 = np.clip(H.diagonal(), opt.min_lm_diagonal, opt.max_lm_diagonal) / radius
+        y = spla.splu((H + sp.diags(D2)).tocsc()).solve(s * grad)
+        m = As @ (-y)
+        model = float(-m @ (rvec + 0.5 * m))
+        rec = dict(iter=it, step_ok=0, cost=cost, cost_change=0.0, gradient_max_norm=gmax, step_norm=0.0,
+                   relative_decrease=0.0, radius=radius)
+        if not np.all(np.isfinite(y)) or not (model > 0.0):
+            invalid_run += 1
+            if invalid_run >= 5:
+                term = 6
+                break
+            radius /= dec
+            dec *= 2.0
+            prev_success = False
+            rec.update(step_ok=-1, radius=radius)
+            recs.append(rec)
+            continue
+        invalid_run = 0
+        delta = np.zeros_like(z)
+        delta[free_idx] = -s * y
+        cand = z + delta
+        cand_cost = ev(cand, False)[0]
+        if not np.isfinite(cand_cost):
+            cand_cost = np.finfo(np.float64).max
+        step_norm = float(np.linalg.norm(delta))
+        cost_change = cost - cand_cost
+        rec.update(step_norm=step_norm, cost_change=cost_change)
+        if step_norm <= opt.ptol * (x_norm + opt.ptol):
+            term = 3
+            recs.append(rec)
+            break
+        if abs(cost_change) <= opt.ftol * cost:
+            term = 1
+            recs.append(rec)
+            break
+        rho = cost_change / model if cand_cost < np.finfo(np.float64).max else -np.inf
+        rec.update(relative_decrease=rho)
+        if rho > opt.min_relative_decrease:
+            z = cand
+            x_norm = float(np.linalg.norm(z[free_idx]))
+            cost, rvec, A = ev(z, True)
+            if not np.isfinite(cost):
+                term = 6
+                break
+            grad = A.T @ rvec
+            gmax = float(np.max(np.abs(grad)))
+            radius = min(opt.max_radius, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3))
+            dec, prev_success = 2.0, True
+            res.successful_steps += 1
+            rec.update(step_ok=1, cost=cost, gradient_max_norm=gmax)
+        else:
+            radius /= dec
+            dec *= 2.0
+            prev_success = False
+            rec.update(step_ok=0, cost=cand_cost)
+        rec.update(radius=radius)
+        recs.append(rec)
+    res.poses = z[:3 * N].reshape(N, 3)
+    sw = np.ones(E)
+    sw[sc] = z[3 * N:]
+    res.switches = sw
+    res.termination, res.iterations, res.final_cost, res.records = term, it, cost, recs
+    return res

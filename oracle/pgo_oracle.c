@@ -307,6 +307,60 @@ double pgo_oracle_eval(int N, const double* poses, int E, const int32_t* ia, con
   return bad ? NAN : cost;
 }
 
+/* METHOD 2, switchable constraints (main.cpp:115-125,138-145; src/ceres_error.cpp:237-317).  Residual blocks:
+ *   odometry edges            OdometryResidue, Huber
+ *   closure + bogus edges     SwitchableClosureResidue  e = s * e_plain(P1,P2)  (3 residuals; params P1, P2, s), Huber
+ *                             SwitchPriorResidue        sqrt(lambda) * (1 - s)  (1 residual; param s), no loss
+ * sw[e] is the switch of edge e (ignored for odometry edges).  Outputs (any may be NULL): r E x 3, J E x 18 (w.r.t. the
+ * poses), Js E x 3 (w.r.t. the switch; 0 for odometry), q E (prior residual; 0 for odometry).  The Huber corrector scales
+ * r, J and Js of a block by the same sqrt(rho').  Returns cost = 1/2 sum rho(|e|^2) + 1/2 sum q^2.                     */
+double pgo_oracle_eval_sc(int N, const double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
+                          const uint8_t* kind, const double* sw, double lambda, double delta, int apply_loss, double* r,
+                          double* J, double* Js, double* q, int threads) {
+  (void)N;
+  double cost = 0.0;
+  int bad = 0;
+  const double sl = sqrt(lambda);
+#ifdef _OPENMP
+  if (threads <= 0) threads = 1;
+#pragma omp parallel for num_threads(threads) reduction(+ : cost) reduction(| : bad) schedule(static)
+#endif
+  for (int e = 0; e < E; ++e) {
+    double ep[3], Jp[18];
+    const double* P1 = poses + 3 * (size_t)ia[e];
+    const double* P2 = poses + 3 * (size_t)ib[e];
+    const int want_j = (J != NULL) || (Js != NULL);
+    if (want_j) edge_functor_jet(P1, P2, meas + 3 * (size_t)e, 0, 0.5, ep, Jp);
+    else edge_functor_double(P1, P2, meas + 3 * (size_t)e, 0, 0.5, ep);
+    const int sc_edge = kind[e] != 0;
+    const double sv = sc_edge ? sw[e] : 1.0;
+    double ee[3] = {sv * ep[0], sv * ep[1], sv * ep[2]};  /* product rule of Jet<7>: d e / d P = s d e_p / d P, d e / d s = e_p */
+    double s2 = ee[0] * ee[0] + ee[1] * ee[1] + ee[2] * ee[2];
+    double rho[3] = {s2, 1.0, 0.0};
+    if (delta > 0.0) huber(s2, delta, rho);
+    cost += 0.5 * rho[0];
+    const double scl = (apply_loss && delta > 0.0) ? sqrt(rho[1]) : 1.0;
+    if (!isfinite(s2)) bad |= 1;
+    double prior = 0.0;
+    if (sc_edge) {
+      prior = sl * (1.0 - sv);
+      cost += 0.5 * prior * prior;
+    }
+    if (q) q[e] = prior;
+    if (r)
+      for (int k = 0; k < 3; ++k) r[3 * (size_t)e + k] = scl * ee[k];
+    if (J)
+      for (int k = 0; k < 18; ++k) {
+        double v = scl * sv * Jp[k];
+        if (!isfinite(v)) bad |= 1;
+        J[18 * (size_t)e + k] = v;
+      }
+    if (Js)
+      for (int k = 0; k < 3; ++k) Js[3 * (size_t)e + k] = sc_edge ? scl * ep[k] : 0.0;
+  }
+  return bad ? NAN : cost;
+}
+
 /* =====================================================================
  * LM + block-Jacobi PCG: the "port" CPU baseline (same algorithm as the HIP
  * backend, plain C + OpenMP).  LM policy = Ceres TrustRegionMinimizer +

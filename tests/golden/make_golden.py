@@ -68,6 +68,20 @@ def main():
                        records=res.records), open(os.path.join(OUT, "lm_%s.json" % tag), "w"), indent=1)
         print(tag, O.TERM[res.termination], res.iterations, res.final_cost)
 
+    # METHOD 2 (switchable constraints): joint LM over poses and switches
+    for name, n_out in [("INTEL", 50), ("M3500", 0), ("MIT", 0)]:
+        gg = O.read_g2o(os.path.join(DATA, name + ".g2o"))
+        if n_out:
+            gg = O.add_random_C(gg, n_out, 1)
+        res = O.lm_direct_sc(gg, O.Options(method=2))
+        tag = "%s_out%d_m2" % (name, n_out)
+        np.save(os.path.join(OUT, "lm_%s_poses.npy" % tag), res.poses)
+        np.save(os.path.join(OUT, "lm_%s_switches.npy" % tag), res.switches)
+        json.dump(dict(dataset=name, outliers=n_out, seed=1, method=2, termination=res.termination,
+                       iterations=res.iterations, initial_cost=res.initial_cost, final_cost=res.final_cost,
+                       records=res.records), open(os.path.join(OUT, "lm_%s.json" % tag), "w"), indent=1)
+        print(tag, O.TERM[res.termination], res.iterations, res.final_cost)
+
 
 if __name__ == "__main__":
     main()

@@ -95,7 +95,7 @@ def test_nonfinite_is_reported(pgo):
 
 def test_unsupported_and_invalid(pgo):
     g = load(pgo, "MIT")
-    for m in (2, 3, 4):
+    for m in (3, 4, -1):
         with pytest.raises(pgo.PgoError) as e:
             pgo.Solver(g, pgo.Options(method=m))
         assert e.value.status == -8
@@ -365,7 +365,7 @@ def test_cli_drop_in(pgo, tmp_path):
     np.testing.assert_array_equal(init[:, 1:], np.array(pgo.ReadG2O(os.path.join(DATA, "INTEL.g2o")).poses))
     edges = np.loadtxt(os.path.join(save, "opt_edges.txt"), dtype=int)
     assert edges.shape == (1533, 3) and list(np.bincount(edges[:, 2])) == [1227, 256, 50]
-    assert subprocess.run([exe, "INTEL", "0", "2"], capture_output=True).returncode == 3
+    assert subprocess.run([exe, "INTEL", "0", "3"], capture_output=True).returncode == 3
 
 
 def test_graph_replay_is_bitwise_identical_to_eager(pgo):
@@ -400,3 +400,81 @@ def test_pose_block_jacobi_sizes_agree(pgo, oracle, name, n_out):
     port = oracle.lm_pcg(og, oracle.Options(method=1, max_iters=6, pcg_rtol=1e-11, pcg_max_iters=200000, pcg_block_poses=32, threads=4))
     assert abs(port.total_pcg_iters - res[32][2]) <= max(5, 0.1 * res[32][2])
     assert np.abs(port.poses - res[32][1]).max() < 2e-6
+
+
+# ------------------------------------------------- METHOD 2: switchable constraints
+@pytest.mark.parametrize("name,n_out", [("INTEL", 50), ("CSAIL", 0), ("MIT", 0)])
+def test_switchable_edge_kernel_parity(pgo, oracle, name, n_out):
+    """e = s e_plain per closure/bogus edge + prior sqrt(lambda)(1 - s) (src/ceres_error.cpp:237-317, main.cpp:115-125)"""
+    g = load(pgo, name, n_out)
+    og = oracle_graph(oracle, g)
+    s = pgo.Solver(g, pgo.Options(method=2))
+    for loss in (True, False):
+        c, r, J = s.evaluate(apply_loss=loss)
+        sw, js = s.switches(want_js=True)
+        oc, orr, oJ, oJs, oq = oracle.evaluate_sc(og, apply_loss=loss)
+        assert c == pytest.approx(oc, rel=1e-12)
+        assert np.abs(r - orr).max() < 1e-11 and np.abs(J - oJ).max() < 1e-11 and np.abs(js - oJs).max() < 1e-11
+        assert np.all(sw == 1.0)
+    # with all switches at 1 and no prior cost this is METHOD 0's objective
+    s0 = pgo.Solver(g, pgo.Options(method=0))
+    assert s0.evaluate(want_r=False, want_J=False)[0] == pytest.approx(c, rel=1e-13)
+    s.close(); s0.close()
+
+
+@pytest.mark.parametrize("name,n_out", [("INTEL", 50), ("M3500", 0), ("MIT", 0)])
+def test_switchable_lm_matches_golden(pgo, name, n_out):
+    """full 50-iteration LM on the joint (poses, switches) problem: the GPU eliminates every switch exactly (per-edge Schur
+    complement) and must reproduce the oracle's joint sparse direct solve -- poses, switches, LM history"""
+    tag = "%s_out%d_m2" % (name, n_out)
+    fx = json.load(open(os.path.join(GOLDEN, "lm_%s.json" % tag)))
+    ref = np.load(os.path.join(GOLDEN, "lm_%s_poses.npy" % tag))
+    ref_sw = np.load(os.path.join(GOLDEN, "lm_%s_switches.npy" % tag))
+    g = load(pgo, name, n_out)
+    s = pgo.Solver(g, pgo.Options(method=2, pcg_max_iters=200000))
+    summ = s.solve()
+    x, sw = s.poses(), s.switches()
+    assert summ.termination == fx["termination"] and summ.iterations == fx["iterations"]
+    assert summ.final_cost == pytest.approx(fx["final_cost"], rel=1e-7)
+    d_xy, d_sw = np.abs(x[:, :2] - ref[:, :2]).max(), np.abs(sw - ref_sw).max()
+    print(f"{tag}: max |d translation| {d_xy:.3e}  max |d switch| {d_sw:.3e}  pcg iters {summ.total_pcg_iters}")
+    assert d_xy < 1e-4 and d_xy < 5e-6 and d_sw < 1e-6
+    assert np.all(sw[np.array(g.kind) == 0] == 1.0)
+    for a, b in zip(s.iter_records(), fx["records"]):
+        assert a["step_ok"] == b["step_ok"]
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-6)
+        assert a["gradient_max_norm"] == pytest.approx(b["gradient_max_norm"], rel=1e-5)
+        assert a["step_norm"] == pytest.approx(b["step_norm"], rel=1e-5, abs=1e-12)
+    s.close()
+
+
+def test_switchable_pose_blocks_and_prior_weight(pgo, oracle):
+    """other preconditioner blocks and another prior weight give the same joint solution as the oracle"""
+    g = load(pgo, "INTEL", 50)
+    og = oracle_graph(oracle, g)
+    ores = oracle.lm_direct_sc(og, oracle.Options(method=2, max_iters=8), lam=4.0)
+    for B in (1, 4, 32):
+        s = pgo.Solver(g, pgo.Options(method=2, max_iters=8, sc_prior_lambda=4.0, pcg_block_poses=B, pcg_max_iters=200000))
+        summ = s.solve()
+        assert summ.final_cost == pytest.approx(ores.final_cost, rel=1e-8)
+        assert np.abs(s.poses() - ores.poses).max() < 1e-6 and np.abs(s.switches() - ores.switches).max() < 1e-7
+        s.close()
+
+
+def test_cli_method2_writes_switches(pgo, tmp_path):
+    import subprocess
+    from importlib import import_module
+    exe = import_module("toy_robust_backend_slam_amd._build").build_cli()
+    save = str(tmp_path / "save")
+    p = subprocess.run([exe, "INTEL", "50", "2", "--seed", "1", "--data", DATA, "--save", save, "--precision", "17"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    ref = np.load(os.path.join(GOLDEN, "lm_INTEL_out50_m2_poses.npy"))
+    got = np.loadtxt(os.path.join(save, "opt_nodes.txt"))
+    assert np.abs(got[:, 1:3] - ref[:, :2]).max() < 1e-4
+    lines = open(os.path.join(save, "switches.txt")).read().splitlines()
+    assert lines[0] == "Odometry EDGES AHEAD" and lines[1228] == "Closure EDGES AHEAD" and lines[1228 + 257] == "BOGUS EDGES AHEAD"
+    assert lines[1].split() == ["0", "1", "0", "1", "1"] and len(lines) == 3 + 1533
+    vals = np.array([float(l.split()[4]) for l in lines[1229:1229 + 256]])
+    ref_sw = np.load(os.path.join(GOLDEN, "lm_INTEL_out50_m2_switches.npy"))
+    assert np.abs(vals - ref_sw[1227:1227 + 256]).max() < 1e-5  # default stream formatting: 6 significant digits

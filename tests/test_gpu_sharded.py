@@ -83,3 +83,18 @@ def test_rccl_backend_single_rank(tmp_path):
     assert res[0]["summary"]["iterations"] == 3
     assert res[0]["summary"]["final_cost"] == pytest.approx(ref[0]["summary"]["final_cost"], rel=1e-10)
     assert np.abs(poses[0] - ref_poses[0]).max() < 1e-8
+
+
+@pytest.mark.parametrize("world,halo", [(2, 0), (3, 1)])
+def test_sharded_switchable_constraints(tmp_path, world, halo):
+    """METHOD 2 across ranks: cut edges keep a replica of their switch on both owners and update it identically"""
+    cfg = dict(graph="INTEL", outliers=50, options=dict(method=2, max_iters=4, pcg_rtol=1e-11, pcg_max_iters=30000))
+    ref, ref_poses = run(1, cfg, tmp_path)
+    cfg = dict(cfg, options=dict(cfg["options"], halo_exchange=halo))
+    res, poses = run(world, cfg, tmp_path, tag="sc%d" % halo)
+    for r in range(world):
+        np.testing.assert_array_equal(poses[r], poses[0])
+        for a, b in zip(res[r]["records"], ref[0]["records"]):
+            assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-9)
+            assert a["gradient_max_norm"] == pytest.approx(b["gradient_max_norm"], rel=1e-7)
+    assert np.abs(poses[0] - ref_poses[0]).max() < 1e-7

@@ -180,3 +180,42 @@ def test_lm_pcg_port_pose_blocks(oracle):
         assert np.abs(a.poses - b.poses).max() < 1e-7 and a.final_cost == pytest.approx(b.final_cost, rel=1e-9)
         its[B] = b.total_pcg_iters
     assert its[32] < its[8] < its[1]
+
+
+def test_switchable_functor_restatement(oracle):
+    """METHOD 2 blocks (src/ceres_error.cpp:237-317): e = s e_plain, d e / d P = s d e_plain / d P, d e / d s = e_plain,
+    prior sqrt(lambda)(1 - s); checked against the plain functor and finite differences in s"""
+    g = oracle.add_random_C(oracle.read_g2o(os.path.join(DATA, "INTEL.g2o")), 20, 1)
+    E = g.n_edges
+    rng = np.random.default_rng(3)
+    sw = np.ones(E)
+    sw[g.kind != 0] = rng.uniform(0.1, 1.0, int((g.kind != 0).sum()))
+    c, r, J, Js, q = oracle.evaluate_sc(g, switches=sw, lam=2.0, apply_loss=False)
+    c0, r0, J0 = oracle.evaluate(g, method=0, apply_loss=False)
+    np.testing.assert_allclose(r, sw[:, None] * r0, rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(J, sw[:, None] * J0, rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(Js[g.kind != 0], r0[g.kind != 0], rtol=1e-14)
+    assert np.all(Js[g.kind == 0] == 0) and np.all(q[g.kind == 0] == 0)
+    np.testing.assert_allclose(q[g.kind != 0], np.sqrt(2.0) * (1 - sw[g.kind != 0]), rtol=1e-15)
+    h = 1e-6
+    k = int(np.nonzero(g.kind != 0)[0][5])
+    swp, swm = sw.copy(), sw.copy()
+    swp[k] += h
+    swm[k] -= h
+    rp = oracle.evaluate_sc(g, switches=swp, lam=2.0, apply_loss=False)[1]
+    rm = oracle.evaluate_sc(g, switches=swm, lam=2.0, apply_loss=False)[1]
+    np.testing.assert_allclose((rp[k] - rm[k]) / (2 * h), Js[k], rtol=1e-8)
+    # Huber corrector scales r, J and Js of a block alike
+    c2, r2, J2, Js2, _ = oracle.evaluate_sc(g, switches=sw, lam=2.0, apply_loss=True)
+    ratio = r2[k] / r[k]
+    np.testing.assert_allclose(Js2[k], ratio[0] * Js[k], rtol=1e-12)
+    assert c2 == c
+
+
+def test_switchable_lm_regression(oracle):
+    g = oracle.add_random_C(oracle.read_g2o(os.path.join(DATA, "INTEL.g2o")), 50, 1)
+    res = oracle.lm_direct_sc(g, oracle.Options(method=2, max_iters=10))
+    fx = json.load(open(os.path.join(GOLDEN, "lm_INTEL_out50_m2.json")))
+    for a, b in zip(res.records, fx["records"][:11]):
+        assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-9)
+    assert res.initial_cost == pytest.approx(3.964897979485657e+01, rel=1e-12)  # == METHOD 0 cost at s = 1

@@ -37,7 +37,8 @@ EXPORTS = [
     "pgo_synth_manhattan", "pgo_options_default",
     "pgo_comm_unique_id", "pgo_comm_create_rccl", "pgo_comm_create_shm", "pgo_comm_destroy",
     "pgo_create", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_solve", "pgo_lm_begin", "pgo_lm_step",
-    "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses",
+    "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
+    "pgo_write_switches",
     "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_debug_spmv", "pgo_debug_normal_eq",
     "pgo_shard_plan", "pgo_shard_halo",
 ]
@@ -58,7 +59,7 @@ class Options(C.Structure):
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
                 ("max_lm_diagonal", C.c_double), ("pcg_rtol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("pcg_check_every", C.c_int32), ("verbose", C.c_int32),
-                ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("sc_prior_lambda", C.c_double), ("reserved", C.c_int32 * 4)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -160,6 +161,8 @@ def lib():
     L.pgo_get_iter_records.argtypes = [vp, C.POINTER(IterRecord), C.c_int32]
     L.pgo_get_poses.argtypes = [vp, dp]
     L.pgo_set_poses.argtypes = [vp, dp]
+    L.pgo_get_switches.argtypes = [vp, dp, dp]
+    L.pgo_write_switches.argtypes = [vp, C.c_char_p, dp]
     L.pgo_bench_eval.argtypes = [vp, C.c_int, C.c_int, C.POINTER(KernelStats)]
     L.pgo_bench_assemble.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
     L.pgo_bench_spmv.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
@@ -297,6 +300,10 @@ class Graph:
     def writePoseGraph_edges(self, path: str):
         _check(lib().pgo_write_edges(self._h, os.fsencode(path)))
 
+    def writePoseGraph_switches(self, path: str, switches):
+        sw = np.ascontiguousarray(switches, np.float64)
+        _check(lib().pgo_write_switches(self._h, os.fsencode(path), _dp(sw)))
+
     def write_g2o(self, path: str):
         _check(lib().pgo_write_g2o(self._h, os.fsencode(path)))
 
@@ -417,6 +424,12 @@ class Solver:
         out = np.zeros((self.n_poses, 3))
         _check(lib().pgo_get_poses(self._h, _dp(out)))
         return out
+
+    def switches(self, want_js=False):
+        sw = np.ones(self.n_edges)
+        js = np.zeros((self.n_edges, 3)) if want_js else None
+        _check(lib().pgo_get_switches(self._h, _dp(sw), _dp(js)))
+        return (sw, js) if want_js else sw
 
     def set_poses(self, poses):
         p = np.ascontiguousarray(poses, np.float64)

@@ -505,6 +505,26 @@ int pgo_write_edges(const pgo_graph* pg, const char* path) {
   return PGO_OK;
 }
 
+int pgo_write_switches(const pgo_graph* pg, const char* path, const double* sw) {
+  if (!pg || !path || !sw) return fail(PGO_ERR_INVALID_ARG, "pgo_write_switches: null argument");
+  FILE* f = fopen(path, "w");
+  if (!f) return fail(PGO_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+  const Graph& g = pg->g;
+  // g2o_util.h:122-146: "<a> <b> <type> <prior> <value>", default ostream formatting (%g), one section per list
+  static const char* head[3] = {"Odometry EDGES AHEAD\n", "Closure EDGES AHEAD\n", "BOGUS EDGES AHEAD\n"};
+  int32_t e = 0;
+  for (int k = 0; k < 3; ++k) {
+    fputs(head[k], f);
+    for (int32_t i = 0; i < g.n_kind[k]; ++i, ++e) {
+      fprintf(f, "%d %d %d %g ", g.pose_id[g.ea[e]], g.pose_id[g.eb[e]], (int)g.kind[e], 1.0);
+      fprintf(f, "%g\n", k == 0 ? 1.0 : sw[e]);
+    }
+  }
+  bool bad = ferror(f);
+  if (fclose(f) != 0 || bad) return fail(PGO_ERR_IO, std::string("write error on ") + path);
+  return PGO_OK;
+}
+
 int pgo_write_g2o(const pgo_graph* pg, const char* path) {
   if (!pg || !path) return fail(PGO_ERR_INVALID_ARG, "pgo_write_g2o: null argument");
   FILE* f = fopen(path, "w");

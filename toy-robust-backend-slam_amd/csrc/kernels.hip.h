@@ -101,11 +101,16 @@ struct EdgeArgs {
   const double* mx;
   const double* my;
   const double* mt;
-  const uint8_t* flags;   // bit0 DCS, bit1 cost counted on this rank
+  const uint8_t* flags;   // bit0 robust edge (DCS for METHOD 1, switchable for METHOD 2), bit1 cost counted on this rank
   int32_t n_edges;
   int32_t apply_loss;
   double phi;
   double huber_delta;
+  // METHOD 2 (switchable constraints, src/ceres_error.cpp:237-317, main.cpp:115-125): e = s e_plain per robust
+  // edge plus the prior sqrt(lambda) (1 - s); nullptr for METHOD 0/1
+  const double* sw;       // [n_edges] switch per local edge
+  double* sw_js;          // [n_edges x 3] out (with the Jacobian): d e / d s after the Huber corrector
+  double sc_lambda;
 };
 
 // One lane per edge.  Algorithmic bytes per edge: 8 (ia,ib) + 24 (meas) + 1 (flags) +
@@ -150,7 +155,17 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
       J[6] = sm;   J[7] = -cm;  J[8] = -sd * pb - cd * pa;  J[9] = -sm;  J[10] = cm;  J[11] = 0.0;
       J[12] = 0.0; J[13] = 0.0; J[14] = -g;                 J[15] = 0.0; J[16] = 0.0; J[17] = g;
     }
-    if (fl & 1u) {  // DCS (src/ceres_error.cpp:185-193): psi = min(1, sqrt(2 phi / (phi + ex^2 + ey^2)))
+    const bool switchable = (fl & 1u) && A.sw != nullptr;
+    double sval = 1.0, epx = 0.0, epy = 0.0, ept = 0.0;
+    if (switchable) {  // e = s e_plain ; d e / d P = s d e_plain / d P ; d e / d s = e_plain
+      sval = A.sw[e];
+      epx = ex; epy = ey; ept = et;
+      ex *= sval; ey *= sval; et *= sval;
+      if (WITH_JAC) {
+#pragma unroll
+        for (int c = 0; c < 18; ++c) J[c] *= sval;
+      }
+    } else if (fl & 1u) {  // DCS (src/ceres_error.cpp:185-193): psi = min(1, sqrt(2 phi / (phi + ex^2 + ey^2)))
       const double res = ex * ex + ey * ey;
       const double psi_org = sqrt(2.0 * A.phi / (A.phi + res));
       if (psi_org < 1.0) {
@@ -181,7 +196,11 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
         if (A.apply_loss) sc = sqrt(rho1);
       }
     }
-    const double ecost = 0.5 * rho0;
+    double ecost = 0.5 * rho0;
+    if (switchable) {  // SwitchPriorResidue: sqrt(lambda) (1 - s), no loss
+      const double q = 1.0 - sval;
+      ecost += 0.5 * A.sc_lambda * q * q;
+    }
     if (fl & 2u) cost = ecost;
     bool finite = isfinite(s);
     if (WITH_JAC) {
@@ -201,6 +220,12 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
       st[11] = sc * ey;
       st[12] = sc * et;
       st[13] = ecost;
+      if (switchable) {
+        double* js = A.sw_js + 3 * e;
+        js[0] = sc * epx;
+        js[1] = sc * epy;
+        js[2] = sc * ept;
+      }
     }
     if (!finite) atomicOr(bad, 1);
   }
@@ -250,6 +275,13 @@ struct AsmArgs {
   double* hoff;              // [(n_inc+63)/64][9][64]: (J_self)'(J_other), row-major 3x3, see hoff_index
   double* hd;                // 6 planes [n_loc]: d00 d01 d02 d11 d12 d22 of (J_self)'(J_self) summed
   double* gs;                // [n_loc x 3]: sum (J_self)' r
+  // METHOD 2 only (k_assemble<true>): per-edge elimination coefficients of the switches (see k_switch_prepare) and the
+  // UNREDUCED diagonal / gradient, which Ceres' LM diagonal and gradient tolerance are defined on
+  const double* sw_js;       // [edges x 3]
+  const double* sw_c;
+  const double* sw_gamma;
+  double* diag_full;         // [n_loc x 3]
+  double* gs_full;           // [n_loc x 3]
 };
 
 // One workgroup per tile of rows.  Phase A: one lane per incidence reads the
@@ -259,8 +291,10 @@ struct AsmArgs {
 // (9 doubles, staged in LDS).  Phase B: one thread per (row, component) sums its
 // row's staged contributions in incidence order -- a fixed order, so the result is
 // bitwise reproducible and independent of the sharding.
+template <bool SC>
 __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
-  __shared__ double scr[9][WG];
+  constexpr int NS = SC ? 15 : 9;  // staged values per incidence
+  __shared__ double scr[NS][WG];
   const int tid = threadIdx.x;
   const XcdRange xr = xcd_range(A.n_tiles);
   for (int t = xr.begin; t < xr.end; t += xr.step) {
@@ -304,23 +338,46 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
           S[3 * k] = x0 * ss[0]; S[3 * k + 1] = x1 * ss[1]; S[3 * k + 2] = x2 * ss[2];
           O[3 * k] = y0 * so[0]; O[3 * k + 1] = y1 * so[1]; O[3 * k + 2] = y2 * so[2];
         }
+        // METHOD 2: elimination coefficients of this edge's switch (c == 0 for ordinary edges)
+        double cc = 0.0, gam = 0.0, vs[3] = {0.0, 0.0, 0.0}, vo[3] = {0.0, 0.0, 0.0};
+        if (SC) {
+          const int64_t le = ed >> 1;
+          cc = A.sw_c[le];
+          if (cc != 0.0) {
+            const double* j = A.sw_js + 3 * le;
+            gam = A.sw_gamma[le];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              vs[a] = S[a] * j[0] + S[3 + a] * j[1] + S[6 + a] * j[2];
+              vo[a] = O[a] * j[0] + O[3 + a] * j[1] + O[6 + a] * j[2];
+            }
+          }
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-          for (int b = 0; b < 3; ++b)
-            A.hoff[hoff_index(3 * a + b, q)] = S[a] * O[b] + S[3 + a] * O[3 + b] + S[6 + a] * O[6 + b];
-        scr[0][tid] = S[0] * S[0] + S[3] * S[3] + S[6] * S[6];
-        scr[1][tid] = S[0] * S[1] + S[3] * S[4] + S[6] * S[7];
-        scr[2][tid] = S[0] * S[2] + S[3] * S[5] + S[6] * S[8];
-        scr[3][tid] = S[1] * S[1] + S[4] * S[4] + S[7] * S[7];
-        scr[4][tid] = S[1] * S[2] + S[4] * S[5] + S[7] * S[8];
-        scr[5][tid] = S[2] * S[2] + S[5] * S[5] + S[8] * S[8];
-        scr[6][tid] = S[0] * R[10] + S[3] * R[11] + S[6] * R[12];
-        scr[7][tid] = S[1] * R[10] + S[4] * R[11] + S[7] * R[12];
-        scr[8][tid] = S[2] * R[10] + S[5] * R[11] + S[8] * R[12];
+          for (int b = 0; b < 3; ++b) {
+            double v = S[a] * O[b] + S[3 + a] * O[3 + b] + S[6 + a] * O[6 + b];
+            if (SC) v -= cc * vs[a] * vo[b];  // J'(I - c j j')J
+            A.hoff[hoff_index(3 * a + b, q)] = v;
+          }
+        double d0 = S[0] * S[0] + S[3] * S[3] + S[6] * S[6], d1 = S[0] * S[1] + S[3] * S[4] + S[6] * S[7];
+        double d2 = S[0] * S[2] + S[3] * S[5] + S[6] * S[8], d3 = S[1] * S[1] + S[4] * S[4] + S[7] * S[7];
+        double d4 = S[1] * S[2] + S[4] * S[5] + S[7] * S[8], d5 = S[2] * S[2] + S[5] * S[5] + S[8] * S[8];
+        double g0 = S[0] * R[10] + S[3] * R[11] + S[6] * R[12], g1 = S[1] * R[10] + S[4] * R[11] + S[7] * R[12];
+        double g2 = S[2] * R[10] + S[5] * R[11] + S[8] * R[12];
+        if (SC) {
+          scr[9][tid] = d0;  scr[10][tid] = d3; scr[11][tid] = d5;   // unreduced diagonal and gradient
+          scr[12][tid] = g0; scr[13][tid] = g1; scr[14][tid] = g2;
+          d0 -= cc * vs[0] * vs[0]; d1 -= cc * vs[0] * vs[1]; d2 -= cc * vs[0] * vs[2];
+          d3 -= cc * vs[1] * vs[1]; d4 -= cc * vs[1] * vs[2]; d5 -= cc * vs[2] * vs[2];
+          g0 -= gam * vs[0]; g1 -= gam * vs[1]; g2 -= gam * vs[2];  // J'(r - gamma j)
+        }
+        scr[0][tid] = d0; scr[1][tid] = d1; scr[2][tid] = d2; scr[3][tid] = d3; scr[4][tid] = d4; scr[5][tid] = d5;
+        scr[6][tid] = g0; scr[7][tid] = g1; scr[8][tid] = g2;
       }
       __syncthreads();
-      for (int idx = tid; idx < nrows * 9; idx += WG) {
+      for (int idx = tid; idx < nrows * NS; idx += WG) {
         const int c = idx / nrows, rl = idx - c * nrows;
         const int row = r0 + rl;
         int lo = A.inc_ptr[row], hi = A.inc_ptr[row + 1];
@@ -332,16 +389,22 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
           acc += s;  // nrows == 1: idx == tid == c
         } else if (c < 6) {
           A.hd[(int64_t)c * A.n_loc + row] = s;
-        } else {
+        } else if (c < 9) {
           A.gs[3 * (int64_t)row + (c - 6)] = s;
+        } else if (c < 12) {
+          A.diag_full[3 * (int64_t)row + (c - 9)] = s;
+        } else {
+          A.gs_full[3 * (int64_t)row + (c - 12)] = s;
         }
       }
       __syncthreads();
       if (q1 == q0) break;
     }
-    if (multi && tid < 9) {
+    if (multi && tid < NS) {
       if (tid < 6) A.hd[(int64_t)tid * A.n_loc + r0] = acc;
-      else A.gs[3 * (int64_t)r0 + (tid - 6)] = acc;
+      else if (tid < 9) A.gs[3 * (int64_t)r0 + (tid - 6)] = acc;
+      else if (tid < 12) A.diag_full[3 * (int64_t)r0 + (tid - 9)] = acc;
+      else A.gs_full[3 * (int64_t)r0 + (tid - 12)] = acc;
     }
   }
 }
@@ -517,16 +580,19 @@ __global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo,
 
 // LM diagonal D'D = clamp(diag(H), min, max) / radius and the block-Jacobi
 // preconditioner M^-1 = (H_ii + D'D)^-1  (symmetric 3x3, 6 planes).
-__global__ void k_prepare(const double* __restrict__ hd, int n_loc, int lo, int fixed, double radius, double dmin,
-                          double dmax, double* __restrict__ d2, double* __restrict__ minv) {
+// diag_full (METHOD 2): the UNREDUCED squared column norms the LM diagonal is defined on; nullptr = hd's diagonal
+__global__ void k_prepare(const double* __restrict__ hd, const double* __restrict__ diag_full, int n_loc, int lo, int fixed,
+                          double radius, double dmin, double dmax, double* __restrict__ d2, double* __restrict__ minv) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_loc) return;
   const int64_t n = n_loc;
   double a00 = hd[row], a01 = hd[n + row], a02 = hd[2 * n + row], a11 = hd[3 * n + row], a12 = hd[4 * n + row],
          a22 = hd[5 * n + row];
-  double e0 = fmin(fmax(a00, dmin), dmax) / radius;
-  double e1 = fmin(fmax(a11, dmin), dmax) / radius;
-  double e2 = fmin(fmax(a22, dmin), dmax) / radius;
+  const double n0 = diag_full ? diag_full[3 * (int64_t)row] : a00, n1 = diag_full ? diag_full[3 * (int64_t)row + 1] : a11,
+               n2 = diag_full ? diag_full[3 * (int64_t)row + 2] : a22;
+  double e0 = fmin(fmax(n0, dmin), dmax) / radius;
+  double e1 = fmin(fmax(n1, dmin), dmax) / radius;
+  double e2 = fmin(fmax(n2, dmin), dmax) / radius;
   if (lo + row == fixed) e0 = e1 = e2 = 1.0;  // decoupled identity row: the constant pose never moves
   d2[3 * (int64_t)row] = e0;
   d2[3 * (int64_t)row + 1] = e1;
@@ -562,9 +628,9 @@ __global__ __launch_bounds__(WG) void k_grad_max(const double* __restrict__ gs, 
 
 // out[k] = reduce(part_k[0..n_k)) for up to 4 partial arrays; one workgroup.
 struct FinArgs {
-  const double* part[4];
-  int32_t n[4];
-  int32_t is_max[4];
+  const double* part[6];
+  int32_t n[6];
+  int32_t is_max[6];
   int32_t count;
   double* out;
 };
@@ -892,6 +958,120 @@ __global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int pa
   if (tid == 0) {
     part_rz[blockIdx.x] = rz;
     part_rr[blockIdx.x] = rr;
+  }
+}
+
+// ------------------------------------------------- METHOD 2: switch variables, eliminated edge by edge
+// A switch s_e appears in exactly two residual blocks (its edge and its prior), so it is eliminated from the LM
+// system exactly (Schur complement per edge).  With sigma = Jacobi scale of the switch column, j = d e / d s,
+//     h_ss = sigma^2 (|j|^2 + lambda),  D_s^2 = clamp(h_ss) / radius,  den = h_ss + D_s^2,
+//     g_s  = sigma (j.r - sqrt(lambda) q)            (scaled gradient w.r.t. the switch; q = sqrt(lambda)(1 - s))
+//     c = sigma^2 / den,  gamma = sigma g_s / den
+// the pose system sees the edge as  J'(I - c j j')J  and  J'(r - gamma j)  (applied in k_assemble), and after the solve
+//     t = j'(J S y),  y_s = (g_s - sigma t) / den,  s_cand = s - sigma y_s.
+struct SwitchArrays {
+  const uint8_t* flags;
+  int32_t n_edges;
+  double lambda;
+  double* sw;      // current switches
+  double* cand;    // candidate switches
+  double* js;      // [n x 3]
+  double* sigma;   // Jacobi scale of the switch column
+  double* c;
+  double* gamma;
+  double* gs;      // scaled gradient g_s
+  double* den;
+  double* hss;
+};
+
+__global__ void k_switch_scale(SwitchArrays W, int enabled) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= W.n_edges) return;
+  double sg = 1.0;
+  if ((W.flags[e] & 1u) && enabled) {
+    const double* j = W.js + 3 * (int64_t)e;
+    sg = 1.0 / (1.0 + sqrt(j[0] * j[0] + j[1] * j[1] + j[2] * j[2] + W.lambda));
+  }
+  W.sigma[e] = sg;
+}
+
+// per LM iteration: elimination coefficients; partial max of the unscaled switch gradient and of sum s^2
+__global__ __launch_bounds__(WG) void k_switch_prepare(SwitchArrays W, const double* __restrict__ jr, double radius, double dmin,
+                                                       double dmax, double* __restrict__ part_gmax,
+                                                       double* __restrict__ part_s2) {
+  __shared__ double red[8];
+  double gm = 0.0, s2 = 0.0;
+  for (int e = blockIdx.x * WG + threadIdx.x; e < W.n_edges; e += gridDim.x * WG) {
+    const unsigned fl = W.flags[e];
+    if (!(fl & 1u)) {
+      W.c[e] = 0.0;
+      W.gamma[e] = 0.0;
+      continue;
+    }
+    const double* j = W.js + 3 * (int64_t)e;
+    const double* r = jr + (int64_t)e * REC + 10;
+    const double sv = W.sw[e], sg = W.sigma[e];
+    const double q = sqrt(W.lambda) * (1.0 - sv);
+    const double gun = j[0] * r[0] + j[1] * r[1] + j[2] * r[2] - sqrt(W.lambda) * q;  // unscaled gradient w.r.t. s
+    const double hss = sg * sg * (j[0] * j[0] + j[1] * j[1] + j[2] * j[2] + W.lambda);
+    const double den = hss + fmin(fmax(hss, dmin), dmax) / radius;
+    W.hss[e] = hss;
+    W.den[e] = den;
+    W.gs[e] = sg * gun;
+    W.c[e] = sg * sg / den;
+    W.gamma[e] = sg * sg * gun / den;
+    if (fl & 2u) {
+      gm = fmax(gm, fabs(gun));
+      s2 += sv * sv;
+    }
+  }
+  gm = block_max_bcast(gm, red);
+  s2 = block_sum_bcast(s2, red);
+  if (threadIdx.x == 0) {
+    part_gmax[blockIdx.x] = gm;
+    part_s2[blockIdx.x] = s2;
+  }
+}
+
+// after the pose solve: back-substitute the switches; partials of the model-decrease terms and of the step norm
+__global__ __launch_bounds__(WG) void k_switch_backsub(SwitchArrays W, const int32_t* __restrict__ ia, const int32_t* __restrict__ ib,
+                                                       const double* __restrict__ jr, const double* __restrict__ scale,
+                                                       const double* __restrict__ yfull, double* __restrict__ part_model,
+                                                       double* __restrict__ part_step2) {
+  __shared__ double red[8];
+  double pm = 0.0, ps = 0.0;
+  for (int e = blockIdx.x * WG + threadIdx.x; e < W.n_edges; e += gridDim.x * WG) {
+    const unsigned fl = W.flags[e];
+    if (!(fl & 1u)) {
+      W.cand[e] = W.sw[e];
+      continue;
+    }
+    const double* R = jr + (int64_t)e * REC;
+    const double* j = W.js + 3 * (int64_t)e;
+    const int64_t a = ia[e], b = ib[e];
+    // (J S y): row k = sum_c A[k][c] sa[c] ya[c] + B[k][c] sb[c] yb[c],  B = [-A[:,0] | -A[:,1] | (0,0,g2)']
+    const double ua0 = scale[3 * a] * yfull[PS * a], ua1 = scale[3 * a + 1] * yfull[PS * a + 1], ua2 = scale[3 * a + 2] * yfull[PS * a + 2];
+    const double ub0 = scale[3 * b] * yfull[PS * b], ub1 = scale[3 * b + 1] * yfull[PS * b + 1], ub2 = scale[3 * b + 2] * yfull[PS * b + 2];
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double row = R[3 * k] * (ua0 - ub0) + R[3 * k + 1] * (ua1 - ub1) + R[3 * k + 2] * ua2 + ((k == 2) ? R[9] * ub2 : 0.0);
+      t += j[k] * row;
+    }
+    const double sg = W.sigma[e], gs = W.gs[e], den = W.den[e];
+    const double ys = (gs - sg * t) / den;
+    W.cand[e] = W.sw[e] - sg * ys;
+    if (fl & 2u) {
+      // joint model decrease = (reduced pose part) + gamma t + y_s g_s - (c t^2 + 2 y_s sigma t + h_ss y_s^2) / 2
+      pm += W.gamma[e] * t + ys * gs - 0.5 * (W.c[e] * t * t + 2.0 * ys * sg * t + W.hss[e] * ys * ys);
+      ps += sg * ys * sg * ys;
+    }
+  }
+  pm = block_sum_bcast(pm, red);
+  ps = block_sum_bcast(ps, red);
+  if (threadIdx.x == 0) {
+    part_model[blockIdx.x] = pm;
+    part_step2[blockIdx.x] = ps;
   }
 }
 

@@ -93,6 +93,12 @@ struct pgo_handle {
   int32_t *halo_send_rows = nullptr, *halo_recv_rows = nullptr;
   double *halo_send_buf = nullptr, *halo_recv_buf = nullptr;
   std::vector<int64_t> halo_send_off3, halo_recv_off3;  // offsets in doubles (3 per row)
+  // METHOD 2: switch variables (one per local edge; only robust edges use theirs), eliminated per edge
+  bool has_sw = false;
+  double *sw = nullptr, *sw_cand = nullptr, *sw_js = nullptr, *sw_sigma = nullptr, *sw_c = nullptr, *sw_gamma = nullptr,
+         *sw_gs = nullptr, *sw_den = nullptr, *sw_hss = nullptr, *diag_full = nullptr, *gs_full = nullptr;
+  double sw_norm2 = 0.0, xnorm2_pose = 0.0;
+  bool sw_fresh = false;  // elimination coefficients / reduced system match the current point AND radius
   // captured slice of PCG iterations (world == 1)
   hipGraphExec_t cg_graph_exec = nullptr;
   int cg_graph_len = 0;
@@ -196,7 +202,7 @@ struct pgo_handle {
   }
 
   // ---- K1
-  dev::EdgeArgs edge_args(const double* x, int apply_loss) const {
+  dev::EdgeArgs edge_args(const double* x, const double* sw_vals, int apply_loss) const {
     dev::EdgeArgs A;
     A.poses = x;
     A.ia = e_ia;
@@ -209,17 +215,36 @@ struct pgo_handle {
     A.apply_loss = apply_loss;
     A.phi = opt.phi;
     A.huber_delta = opt.huber_delta;
+    A.sw = has_sw ? sw_vals : nullptr;
+    A.sw_js = sw_js;
+    A.sc_lambda = opt.sc_prior_lambda;
     return A;
   }
-  void launch_eval(const double* x, int apply_loss, bool with_jac) {
-    dev::EdgeArgs A = edge_args(x, apply_loss);
+  dev::SwitchArrays switch_arrays() const {
+    dev::SwitchArrays W;
+    W.flags = e_flags;
+    W.n_edges = S.n_edges_local;
+    W.lambda = opt.sc_prior_lambda;
+    W.sw = sw;
+    W.cand = sw_cand;
+    W.js = sw_js;
+    W.sigma = sw_sigma;
+    W.c = sw_c;
+    W.gamma = sw_gamma;
+    W.gs = sw_gs;
+    W.den = sw_den;
+    W.hss = sw_hss;
+    return W;
+  }
+  void launch_eval(const double* x, const double* sw_vals, int apply_loss, bool with_jac) {
+    dev::EdgeArgs A = edge_args(x, sw_vals, apply_loss);
     if (with_jac) hipLaunchKernelGGL(dev::k_edge_eval<true>, dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
     else hipLaunchKernelGGL(dev::k_edge_eval<false>, dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
   }
   // evaluates at x; on return h_scal[slot] = cost, h_scal[slot+1] = #bad flags (needs fetch by caller)
-  int eval_enqueue(const double* x, int apply_loss, bool with_jac, int slot) {
+  int eval_enqueue(const double* x, const double* sw_vals, int apply_loss, bool with_jac, int slot) {
     HIPC(hipMemsetAsync(bad, 0, sizeof(int), stream));
-    launch_eval(x, apply_loss, with_jac);
+    launch_eval(x, sw_vals, apply_loss, with_jac);
     PGOC(check_launch("k_edge_eval"));
     // the flag rides along as a "partial array" of length 1 after conversion to double
     hipLaunchKernelGGL(dev::k_flag_to_double, dim3(1), dim3(1), 0, stream, bad, part[4]);
@@ -242,11 +267,17 @@ struct pgo_handle {
     A.hoff = hoff;
     A.hd = hd;
     A.gs = gs;
+    A.sw_js = sw_js;
+    A.sw_c = sw_c;
+    A.sw_gamma = sw_gamma;
+    A.diag_full = diag_full;
+    A.gs_full = gs_full;
     return A;
   }
   int assemble_enqueue() {
     if (S.n_tiles() == 0) return PGO_OK;
-    hipLaunchKernelGGL(dev::k_assemble, dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
+    if (has_sw) hipLaunchKernelGGL(dev::k_assemble<true>, dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
+    else hipLaunchKernelGGL(dev::k_assemble<false>, dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
     return check_launch("k_assemble");
   }
 
@@ -297,7 +328,8 @@ struct pgo_handle {
 
   int create(int32_t N, const double* poses_h, int32_t E, const int32_t* ia, const int32_t* ib, const double* meas,
              const uint8_t* kind);
-  int linearize(bool reuse_records);
+  int linearize(bool reuse_records, bool assemble = true);
+  int refresh_switch_system();
   int lm_begin();
   int lm_iteration(bool* stop);
   int pcg(int* iters, double* rel);
@@ -343,6 +375,13 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(dalloc(&r, 3 * NL));
   PGOC(dalloc(&z, 3 * NL));
   PGOC(dalloc(&ap, 3 * NL));
+  has_sw = (opt.method == 2);
+  if (has_sw) {
+    for (double** ptr : {&sw, &sw_cand, &sw_sigma, &sw_c, &sw_gamma, &sw_gs, &sw_den, &sw_hss}) PGOC(dalloc(ptr, EL));
+    PGOC(dalloc(&sw_js, 3 * EL));
+    PGOC(dalloc(&diag_full, 3 * NL));
+    PGOC(dalloc(&gs_full, 3 * NL));
+  }
   PGOC(dalloc(&st, 1));
   PGOC(dalloc(&scal, N_SCAL));
   PGOC(dalloc(&bad, 1));
@@ -371,6 +410,12 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(upload(inc_edge, S.inc_edge));
   PGOC(upload(inc_col, S.inc_col));
   PGOC(upload(tile_row, S.tile_row));
+  if (has_sw) {  // switches start at 1.0 (main.cpp:117,139)
+    std::vector<double> ones((size_t)EL, 1.0);
+    PGOC(upload(sw, ones));
+    PGOC(upload(sw_cand, ones));
+    PGOC(sync());  // `ones` dies with this scope
+  }
   // halo lists for the point-to-point exchange of the search direction
   use_halo = world > 1 && opt.halo_exchange != 0;
   if (use_halo) {
@@ -409,18 +454,40 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
 
 // evaluate (K1, unscaled records) + assemble (K2, applies the current `scale`) at `poses`;
 // leaves cost/bad in h_scal[0..1]
-int pgo_handle::linearize(bool reuse_records) {
+int pgo_handle::linearize(bool reuse_records, bool assemble) {
   double t0 = wall_s();
   if (!reuse_records) {
-    PGOC(eval_enqueue(poses, 1, true, 0));
+    PGOC(eval_enqueue(poses, sw, 1, true, 0));
     PGOC(fetch_scal(0, 2));
     t_eval += wall_s() - t0;
     if (h_scal[1] > 0.0 || !std::isfinite(h_scal[0])) return fail(PGO_ERR_NUMERIC, "residual/Jacobian evaluation produced non-finite values");
   }
+  if (!assemble) return PGO_OK;
   t0 = wall_s();
   PGOC(assemble_enqueue());
   PGOC(sync());
   t_asm += wall_s() - t0;
+  return PGO_OK;
+}
+
+// METHOD 2, at the top of every LM iteration (the radius has changed): elimination coefficients of the switches for
+// the current radius, re-assembly of the reduced pose system, gradient max-norm over poses AND switches, sum s^2.
+int pgo_handle::refresh_switch_system() {
+  const int g_sw = std::min(std::max(1, (S.n_edges_local + dev::WG - 1) / dev::WG), 1024);
+  hipLaunchKernelGGL(dev::k_switch_prepare, dim3(g_sw), dim3(dev::WG), 0, stream, switch_arrays(), (const double*)jr, radius,
+                     opt.min_lm_diagonal, opt.max_lm_diagonal, part[2], part[3]);
+  PGOC(check_launch("k_switch_prepare"));
+  PGOC(assemble_enqueue());
+  hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, (const double*)gs_full, (const double*)scale, S.n_loc,
+                     S.lo, part[0]);
+  PGOC(check_launch("k_grad_max"));
+  PGOC(reduce_to_scal({{part[0], g_flat, 1}, {part[2], g_sw, 1}}, 10, true));
+  PGOC(reduce_to_scal({{part[3], g_sw, 0}}, 12));
+  PGOC(fetch_scal(10, 3));
+  gmax = std::max(h_scal[10], h_scal[11]);
+  sw_norm2 = h_scal[12];
+  x_norm = std::sqrt(xnorm2_pose + sw_norm2);
+  sw_fresh = true;
   return PGO_OK;
 }
 
@@ -441,12 +508,25 @@ int pgo_handle::lm_begin() {
   const double t_begin = wall_s();
   t_total = 0;
   const int fixed = opt.fixed_pose;
+  if (has_sw) {  // switches start at 1.0 (main.cpp:117,139); nothing eliminated yet
+    std::vector<double> ones((size_t)std::max(1, S.n_edges_local), 1.0);
+    HIPC(hipMemcpyAsync(sw, ones.data(), (size_t)S.n_edges_local * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIPC(hipMemcpyAsync(sw_cand, ones.data(), (size_t)S.n_edges_local * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIPC(hipMemsetAsync(sw_c, 0, (size_t)S.n_edges_local * sizeof(double), stream));
+    HIPC(hipMemsetAsync(sw_gamma, 0, (size_t)S.n_edges_local * sizeof(double), stream));
+    PGOC(sync());  // `ones` dies with this scope
+  }
   // pass 1: unit scales (0 on the constant pose) -> column norms for Jacobi scaling
   hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 0, scale);
   PGOC(check_launch("k_jacobi_scale"));
   PGOC(allgather(scale));
   PGOC(linearize(false));
   const double cost0 = h_scal[0];
+  if (has_sw) {  // Jacobi scale of the switch columns from the iteration-0 Jacobian
+    hipLaunchKernelGGL(dev::k_switch_scale, dim3((S.n_edges_local + 255) / 256 + 1), dim3(256), 0, stream, switch_arrays(),
+                       opt.jacobi_scaling);
+    PGOC(check_launch("k_switch_scale"));
+  }
   if (opt.jacobi_scaling) {
     hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 1, scale);
     PGOC(check_launch("k_jacobi_scale"));
@@ -462,7 +542,10 @@ int pgo_handle::lm_begin() {
   PGOC(reduce_to_scal({{part[1], g_flat, 0}}, 3));
   PGOC(fetch_scal(2, 2));
   gmax = h_scal[2];
-  x_norm = std::sqrt(h_scal[3]);
+  xnorm2_pose = h_scal[3];
+  x_norm = std::sqrt(xnorm2_pose);
+  sw_fresh = false;
+  if (has_sw) PGOC(refresh_switch_system());
   lin_valid = true;
   pgo_iter_record R;
   memset(&R, 0, sizeof R);
@@ -572,6 +655,7 @@ int pgo_handle::lm_iteration(bool* stop) {
     *stop = true;
     return PGO_OK;
   }
+  if (has_sw && !sw_fresh) PGOC(refresh_switch_system());  // the radius changed since the last assembly (rejected / invalid step)
   if (prev_success && gmax <= opt.gtol) {
     termination = PGO_TERM_CONVERGENCE_GTOL;
     *stop = true;
@@ -590,7 +674,7 @@ int pgo_handle::lm_iteration(bool* stop) {
 
   // LM diagonal + preconditioner, then the linear solve
   double t0 = wall_s();
-  hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, opt.fixed_pose, radius,
+  hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, (const double*)diag_full, S.n_loc, S.lo, opt.fixed_pose, radius,
                      opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv);
   PGOC(check_launch("k_prepare"));
   if (grp_B > 1) {
@@ -626,11 +710,24 @@ int pgo_handle::lm_iteration(bool* stop) {
   double* x_old = poses;
   hipLaunchKernelGGL(dev::k_candidate, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, x_old, scale, y, cand, part[3]);
   PGOC(check_launch("k_candidate"));
+  double model_sw = 0.0, step2_sw = 0.0;
+  if (has_sw) {  // back-substitute the switches (needs y of both endpoints: in the gather vector after the share above)
+    const int g_sw = std::min(std::max(1, (S.n_edges_local + dev::WG - 1) / dev::WG), 1024);
+    hipLaunchKernelGGL(dev::k_switch_backsub, dim3(g_sw), dim3(dev::WG), 0, stream, switch_arrays(), (const int32_t*)e_ia,
+                       (const int32_t*)e_ib, (const double*)jr, (const double*)scale, (const double*)p_full, part[2], part[4]);
+    PGOC(check_launch("k_switch_backsub"));
+    PGOC(reduce_to_scal({{part[2], g_sw, 0}, {part[4], g_sw, 0}}, 13));
+  }
   PGOC(reduce_to_scal({{part[1], g_flat, 0}, {part[0], g_spmv, 0}, {part[3], g_flat, 0}}, 0));
   PGOC(fetch_scal(0, 3));
+  if (has_sw) {
+    PGOC(fetch_scal(13, 2));
+    model_sw = h_scal[13];
+    step2_sw = h_scal[14];
+  }
   t_lin += wall_s() - t0;
-  const double ydotg = h_scal[0], yHy = h_scal[1], step2 = h_scal[2];
-  const double model = ydotg - 0.5 * yHy;
+  const double ydotg = h_scal[0], yHy = h_scal[1], step2 = h_scal[2] + step2_sw;
+  const double model = ydotg - 0.5 * yHy + model_sw;
   if (!std::isfinite(model) || !std::isfinite(step2) || !(model > 0.0)) {  // invalid step
     if (++invalid_run >= 5) {
       termination = PGO_TERM_FAILURE;
@@ -639,6 +736,7 @@ int pgo_handle::lm_iteration(bool* stop) {
     }
     radius /= decrease_factor;
     decrease_factor *= 2.0;
+    sw_fresh = false;
     prev_success = 0;
     R.step_ok = -1;
     R.cost = cost;
@@ -652,7 +750,7 @@ int pgo_handle::lm_iteration(bool* stop) {
   invalid_run = 0;
   t0 = wall_s();
   PGOC(allgather(cand));
-  PGOC(eval_enqueue(cand, 1, false, 0));
+  PGOC(eval_enqueue(cand, sw_cand, 1, false, 0));
   PGOC(fetch_scal(0, 2));
   t_cand += wall_s() - t0;
   double cand_cost = h_scal[0];
@@ -681,25 +779,33 @@ int pgo_handle::lm_iteration(bool* stop) {
   R.relative_decrease = rho;
   if (rho > opt.min_relative_decrease) {  // HandleSuccessfulStep
     std::swap(poses, cand);
+    if (has_sw) std::swap(sw, sw_cand);
     hipLaunchKernelGGL(dev::k_xnorm, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, poses, scale, part[1]);
     PGOC(check_launch("k_xnorm"));
     PGOC(reduce_to_scal({{part[1], g_flat, 0}}, 3));
-    int st_lin = linearize(false);
+    int st_lin = linearize(false, !has_sw);  // METHOD 2 assembles in refresh_switch_system(), with the new radius
     if (st_lin == PGO_ERR_NUMERIC) {
       finish(PGO_TERM_FAILURE);
       return PGO_OK;
     }
     PGOC(st_lin);
     cost = h_scal[0];
-    hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
-    PGOC(check_launch("k_grad_max"));
-    PGOC(reduce_to_scal({{part[0], g_flat, 1}}, 2, true));
-    PGOC(fetch_scal(2, 2));
-    gmax = h_scal[2];
-    x_norm = std::sqrt(h_scal[3]);
     const double t = 2.0 * rho - 1.0;
     radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
     radius = std::min(opt.max_radius, radius);
+    if (has_sw) {
+      PGOC(fetch_scal(3, 1));
+      xnorm2_pose = h_scal[3];
+      PGOC(refresh_switch_system());  // gmax over poses and switches, x_norm, reduced system for the next iteration
+    } else {
+      hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
+      PGOC(check_launch("k_grad_max"));
+      PGOC(reduce_to_scal({{part[0], g_flat, 1}}, 2, true));
+      PGOC(fetch_scal(2, 2));
+      gmax = h_scal[2];
+      xnorm2_pose = h_scal[3];
+      x_norm = std::sqrt(xnorm2_pose);
+    }
     decrease_factor = 2.0;
     prev_success = 1;
     ++successful;
@@ -709,6 +815,7 @@ int pgo_handle::lm_iteration(bool* stop) {
   } else {  // HandleUnsuccessfulStep
     radius /= decrease_factor;
     decrease_factor *= 2.0;
+    sw_fresh = false;
     prev_success = 0;
     R.step_ok = 0;
     R.cost = cand_cost;
@@ -777,6 +884,7 @@ void pgo_options_default(pgo_options* o) {
   o->pcg_check_every = 50;
   o->verbose = 0;
   o->use_graphs = 1;
+  o->sc_prior_lambda = 1.0;
 }
 
 int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
@@ -786,8 +894,8 @@ int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges,
   pgo_options o;
   if (opt) o = *opt;
   else pgo_options_default(&o);
-  if (o.method != 0 && o.method != 1)
-    return fail(PGO_ERR_UNSUPPORTED, "only METHOD 0 (plain) and 1 (DCS) are implemented (reference main.cpp:54-56)");
+  if (o.method < 0 || o.method > 2)
+    return fail(PGO_ERR_UNSUPPORTED, "only METHOD 0 (plain), 1 (DCS) and 2 (switchable constraints) are implemented (reference main.cpp:54-56)");
   if (o.fixed_pose >= n_poses) return fail(PGO_ERR_INVALID_ARG, "fixed_pose out of range");
   PGOC(require_device(device));
   std::unique_ptr<pgo_handle> H(new pgo_handle);
@@ -824,6 +932,30 @@ int pgo_get_poses(pgo_t* h, double* out) {
   return h->sync();
 }
 
+int pgo_get_switches(pgo_t* h, double* switches, double* js_out) {
+  if (!h || !switches) return fail(PGO_ERR_INVALID_ARG, "pgo_get_switches: null");
+  if (h->comm && h->comm->world > 1) return fail(PGO_ERR_UNSUPPORTED, "pgo_get_switches: world == 1 only");
+  HIPC(hipSetDevice(h->device));
+  const int64_t EL = h->S.n_edges_local;
+  if (!h->has_sw) {
+    for (int64_t k = 0; k < EL; ++k) switches[h->S.orig_edge[k]] = 1.0;
+    if (js_out) memset(js_out, 0, (size_t)3 * EL * sizeof(double));
+    return PGO_OK;
+  }
+  std::vector<double> v((size_t)EL), j((size_t)3 * EL);
+  HIPC(hipMemcpyAsync(v.data(), h->sw, v.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipMemcpyAsync(j.data(), h->sw_js, j.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PGOC(h->sync());
+  for (int64_t k = 0; k < EL; ++k) {
+    const int64_t e = h->S.orig_edge[k];
+    const bool robust = h->S.flags[k] & 1;
+    switches[e] = robust ? v[k] : 1.0;
+    if (js_out)
+      for (int c = 0; c < 3; ++c) js_out[3 * e + c] = robust ? j[3 * k + c] : 0.0;
+  }
+  return PGO_OK;
+}
+
 int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss, double* cost, double* r_out, double* J_out) {
   if (!h) return fail(PGO_ERR_INVALID_ARG, "pgo_eval: null handle");
   HIPC(hipSetDevice(h->device));
@@ -838,7 +970,7 @@ int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss, double* cost
     h->lin_valid = false;  // the record buffer is about to be overwritten
     h->lm_active = false;
   }
-  PGOC(h->eval_enqueue(x, apply_loss, want_jac, 0));
+  PGOC(h->eval_enqueue(x, h->sw, apply_loss, want_jac, 0));
   PGOC(h->fetch_scal(0, 2));
   if (cost) *cost = h->h_scal[0];
   if (want_jac) {
@@ -963,7 +1095,7 @@ int pgo_bench_eval(pgo_t* h, int reps, int with_jacobian, pgo_kernel_stats* out)
   if (!h || !out || reps < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_eval: bad argument");
   HIPC(hipSetDevice(h->device));
   double ms = 0;
-  PGOC(time_launches(h, reps, [&] { h->launch_eval(h->poses, 1, with_jacobian != 0); }, &ms));
+  PGOC(time_launches(h, reps, [&] { h->launch_eval(h->poses, h->sw, 1, with_jacobian != 0); }, &ms));
   out->ms_avg = ms;
   out->units = h->S.n_edges_local;
   // 84 B read per edge + the record (here 112 B: DESIGN.md section 2); 84 + 8 without

@@ -104,7 +104,8 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
     S->my[k] = meas[3 * (size_t)e + 1];
     S->mt[k] = meas[3 * (size_t)e + 2];
     // DCS on closure + bogus edges only when METHOD == 1 (reference main.cpp:112-114,135-137)
-    uint8_t f = (method == 1 && kind[e] != PGO_EDGE_ODOMETRY) ? 1 : 0;
+    // ... and the switchable functor on the same edges when METHOD == 2 (main.cpp:115-125,138-145)
+    uint8_t f = ((method == 1 || method == 2) && kind[e] != PGO_EDGE_ODOMETRY) ? 1 : 0;
     if (owned(ia[e])) f |= 2;
     S->flags[k] = f;
     if (!(owned(ia[e]) && owned(ib[e]))) S->n_cut++;

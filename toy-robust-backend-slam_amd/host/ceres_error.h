@@ -11,8 +11,9 @@
 
 namespace pgo {
 struct CostFunction {   // stands in for ceres::CostFunction* on this path
-  double dx, dy, dtheta;
-  bool dcs;
+  enum Kind { PLAIN, DCS, SWITCHABLE, SWITCH_PRIOR };
+  double dx, dy, dtheta;   // SWITCH_PRIOR: dx holds lambda
+  Kind kind;
 };
 }  // namespace pgo
 
@@ -37,7 +38,7 @@ struct OdometryResidue {
     pgo_detail::se2_error(P1, P2, dx, dy, dtheta, e);
     return true;
   }
-  static pgo::CostFunction* Create(double dx, double dy, double dtheta) { return new pgo::CostFunction{dx, dy, dtheta, false}; }
+  static pgo::CostFunction* Create(double dx, double dy, double dtheta) { return new pgo::CostFunction{dx, dy, dtheta, pgo::CostFunction::PLAIN}; }
   double dx, dy, dtheta;
 };
 
@@ -57,8 +58,36 @@ struct DCSClosureResidue {
     }
     return true;
   }
-  static pgo::CostFunction* Create(double dx, double dy, double dtheta) { return new pgo::CostFunction{dx, dy, dtheta, true}; }
+  static pgo::CostFunction* Create(double dx, double dy, double dtheta) { return new pgo::CostFunction{dx, dy, dtheta, pgo::CostFunction::DCS}; }
   double dx, dy, dtheta;
+};
+
+// Switchable constraints (reference include/ceres_error.h:38-66, src/ceres_error.cpp:199-317)
+struct SwitchableClosureResidue {
+  SwitchableClosureResidue(double dx_, double dy_, double dtheta_) : dx(dx_), dy(dy_), dtheta(dtheta_) {}
+  template <typename T>
+  bool operator()(const T* const P1, const T* const P2, const T* const S, T* e) const {
+    pgo_detail::se2_error(P1, P2, dx, dy, dtheta, e);
+    e[0] = S[0] * e[0];
+    e[1] = S[0] * e[1];
+    e[2] = S[0] * e[2];
+    return true;
+  }
+  static pgo::CostFunction* Create(double dx, double dy, double dtheta) {
+    return new pgo::CostFunction{dx, dy, dtheta, pgo::CostFunction::SWITCHABLE};
+  }
+  double dx, dy, dtheta;
+};
+
+struct SwitchPriorResidue {
+  explicit SwitchPriorResidue(double lambda_) : lambda(lambda_) {}
+  template <typename T>
+  bool operator()(const T* const S, T* e) const {
+    e[0] = T(std::sqrt(lambda)) * (T(1.0) - S[0]);
+    return true;
+  }
+  static pgo::CostFunction* Create(double lambda) { return new pgo::CostFunction{lambda, 0.0, 0.0, pgo::CostFunction::SWITCH_PRIOR}; }
+  double lambda;
 };
 
 #endif

@@ -57,6 +57,17 @@ class ReadG2O {
     check(pgo_write_edges(g_, fname.c_str()));
   }
 
+  // g2o_util.h:114-148 of the reference: priors[i] / *optimized[i] per closure then bogus edge
+  void writePoseGraph_switches(const std::string& fname, std::vector<double>& priors, std::vector<double*>& optimized) {
+    std::cout << "#Closure Edges : " << nEdgesClosure.size() << std::endl;
+    std::cout << "#Bogus Edges : " << nEdgesBogus.size() << std::endl;
+    std::cout << "#priors : " << priors.size() << std::endl;
+    std::cout << "#optimized " << optimized.size() << std::endl;
+    std::vector<double> sw(nEdgesOdometry.size(), 1.0);
+    for (double* s : optimized) sw.push_back(*s);
+    check(pgo_write_switches(g_, fname.c_str(), sw.data()));
+  }
+
   std::vector<Node*> nNodes;
   std::vector<Edge*> nEdgesOdometry;
   std::vector<Edge*> nEdgesClosure;

@@ -39,11 +39,36 @@ class Problem {
     ia_.push_back(block(p1));
     ib_.push_back(block(p2));
     meas_.insert(meas_.end(), {cost->dx, cost->dy, cost->dtheta});
-    kind_.push_back(cost->dcs ? PGO_EDGE_CLOSURE : PGO_EDGE_ODOMETRY);
-    any_dcs_ = any_dcs_ || cost->dcs;
+    if (cost->kind == CostFunction::SWITCHABLE || cost->kind == CostFunction::SWITCH_PRIOR)
+      throw std::invalid_argument("switchable blocks take the (P1, P2, S) / (S) overloads");
+    const bool dcs = cost->kind == CostFunction::DCS;
+    kind_.push_back(dcs ? PGO_EDGE_CLOSURE : PGO_EDGE_ODOMETRY);
+    switch_.push_back(nullptr);
+    any_dcs_ = any_dcs_ || dcs;
     const double d = loss ? loss->huber_delta() : 0.0;
     if (!ia_.empty() && ia_.size() > 1 && d != delta_) mixed_loss_ = true;
     delta_ = d;
+  }
+  // SwitchableClosureResidue: (P1, P2, S)  (reference main.cpp:122,143)
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* p1, double* p2, double* s) {
+    std::unique_ptr<CostFunction> own(cost);
+    if (cost->kind != CostFunction::SWITCHABLE) throw std::invalid_argument("three parameter blocks: SwitchableClosureResidue only");
+    if (p1 == p2) throw std::invalid_argument("duplicate parameter block in a residual block");
+    ia_.push_back(block(p1));
+    ib_.push_back(block(p2));
+    meas_.insert(meas_.end(), {cost->dx, cost->dy, cost->dtheta});
+    kind_.push_back(PGO_EDGE_CLOSURE);
+    switch_.push_back(s);
+    any_sc_ = true;
+    const double d = loss ? loss->huber_delta() : 0.0;
+    if (ia_.size() > 1 && d != delta_) mixed_loss_ = true;
+    delta_ = d;
+  }
+  // SwitchPriorResidue: (S), no loss  (reference main.cpp:124-125,144-145)
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* s) {
+    std::unique_ptr<CostFunction> own(cost);
+    if (cost->kind != CostFunction::SWITCH_PRIOR || loss) throw std::invalid_argument("one parameter block: SwitchPriorResidue without loss only");
+    prior_lambda_[s] = cost->dx;
   }
   void SetParameterBlockConstant(double* p) { fixed_ = block(p); }
   int NumResidualBlocks() const { return (int)ia_.size(); }
@@ -66,7 +91,9 @@ class Problem {
   std::vector<uint8_t> kind_;
   int32_t fixed_ = -1;
   double delta_ = 0.0;
-  bool any_dcs_ = false, mixed_loss_ = false;
+  std::vector<double*> switch_;                    // per residual block: its switch variable or nullptr
+  std::unordered_map<double*, double> prior_lambda_;  // switch -> lambda of its prior
+  bool any_dcs_ = false, any_sc_ = false, mixed_loss_ = false;
 };
 
 namespace Solver {
@@ -113,7 +140,20 @@ struct SolverAccess {
       for (int k = 0; k < 3; ++k) poses[3 * (size_t)i + k] = pr->ptr_[i][k];
     pgo_options o;
     pgo_options_default(&o);
-    o.method = pr->any_dcs_ ? 1 : 0;
+    if (pr->any_sc_ && pr->any_dcs_) throw std::invalid_argument("DCS and switchable blocks cannot be mixed (the reference's METHOD is one of them)");
+    o.method = pr->any_sc_ ? 2 : (pr->any_dcs_ ? 1 : 0);
+    if (pr->any_sc_) {  // every switch needs exactly its prior, all with one lambda (as main.cpp:107)
+      double lam = -1.0;
+      for (double* sp : pr->switch_) {
+        if (!sp) continue;
+        auto it = pr->prior_lambda_.find(sp);
+        if (it == pr->prior_lambda_.end()) throw std::invalid_argument("a switch variable has no SwitchPriorResidue");
+        if (lam >= 0.0 && it->second != lam) throw std::invalid_argument("this backend needs one lambda for all switch priors");
+        lam = it->second;
+        if (*sp != 1.0) throw std::invalid_argument("switch variables must start at 1.0 (main.cpp:117,139)");
+      }
+      o.sc_prior_lambda = lam;
+    }
     o.huber_delta = pr->delta_;
     o.fixed_pose = pr->fixed_;
     o.max_iters = opt.max_num_iterations;
@@ -131,6 +171,8 @@ struct SolverAccess {
     check(pgo_create(&h, N, poses.data(), E, pr->ia_.data(), pr->ib_.data(), pr->meas_.data(), pr->kind_.data(), &o, nullptr, opt.device));
     int st = pgo_solve(h, &sum->s);
     if (st == PGO_OK) st = pgo_get_poses(h, poses.data());
+    std::vector<double> sw((size_t)E, 1.0);
+    if (st == PGO_OK && pr->any_sc_) st = pgo_get_switches(h, sw.data(), nullptr);
     if (st == PGO_OK) {
       sum->iterations.resize((size_t)pgo_num_iter_records(h));
       st = pgo_get_iter_records(h, sum->iterations.data(), (int32_t)sum->iterations.size());
@@ -139,6 +181,8 @@ struct SolverAccess {
     check(st);
     for (int32_t i = 0; i < N; ++i)  // in place, like Ceres
       for (int k = 0; k < 3; ++k) pr->ptr_[i][k] = poses[3 * (size_t)i + k];
+    for (int32_t e = 0; e < E; ++e)
+      if (pr->switch_[e]) *pr->switch_[e] = sw[(size_t)e];
     sum->num_parameter_blocks = N;
     sum->num_residual_blocks = E;
   }
