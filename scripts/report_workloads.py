@@ -24,7 +24,8 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     threads = min(16, os.cpu_count() or 1)
     rows = []
-    for name, n_out, method in [("INTEL", 50, 1), ("INTEL", 50, 0), ("M3500", 0, 1), ("M3500", 0, 0), ("MIT", 0, 1), ("MIT", 0, 0)]:
+    for name, n_out, method in [("INTEL", 50, 1), ("INTEL", 50, 0), ("INTEL", 50, 2), ("M3500", 0, 1), ("M3500", 0, 0), ("M3500", 0, 2),
+                                ("MIT", 0, 1), ("MIT", 0, 0), ("MIT", 0, 2)]:
         g = P.ReadG2O(os.path.join(ROOT, "tests", "golden", "data", name + ".g2o"))
         if n_out:
             g.add_random_C(n_out, 1)
@@ -37,7 +38,7 @@ def main():
         x = s.poses()
         s.close()
         t = time.perf_counter()
-        ores = O.lm_direct(og(g), O.Options(method=method))
+        ores = O.lm_direct_sc(og(g), O.Options(method=2)) if method == 2 else O.lm_direct(og(g), O.Options(method=method))
         odt = time.perf_counter() - t
         rows.append(dict(workload="%s +%d outliers, METHOD %d" % (name, n_out, method), poses=g.n_poses, edges=g.n_edges,
                          policy="exact (PCG rtol 1e-10, 32-pose blocks)", lm_iters=summ.iterations, pcg_iters=summ.total_pcg_iters,
