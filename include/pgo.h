@@ -155,7 +155,11 @@ typedef struct pgo_options {
                                   1 = point-to-point halo exchange: every rank sends each peer only the rows that
                                       peer's off-diagonal blocks reference (ncclSend/ncclRecv group)            */
   double  sc_prior_lambda;     /* 1.0  METHOD 2: weight of the switch prior sqrt(lambda)(1 - s)  (main.cpp:107)    */
-  int32_t reserved[4];
+  int32_t pose_ordering;       /* internal numbering of the poses (results are always in the caller's numbering):
+                                  0 = the caller's, 1 = locality ordering (pgo_pose_order: segments of 64 consecutive
+                                  poses reordered by reverse Cuthill-McKee on the loop edges that a neighbouring edge
+                                  supports), -1 (default) = 1 when world > 1 (it shrinks every rank's halo), else 0  */
+  int32_t reserved[3];
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */
@@ -273,6 +277,14 @@ int pgo_debug_normal_eq(pgo_t* h, double* g_or_null, double* hdiag_or_null);    
 int pgo_shard_plan(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
                    int world, int rank, int row_align, int32_t* lo, int32_t* hi,
                    int32_t* n_local_edges, int32_t* n_cut_edges);                 /* [host] */
+/* Locality ordering of the poses, the permutation the solver applies internally when pose_ordering = 1:
+ * perm[i] = new position of pose i.  Segments of `segment` consecutive poses stay contiguous and in order (the
+ * odometry chain and the preconditioner's pose blocks survive; `segment` should be a multiple of the block size);
+ * the segments are reordered by reverse Cuthill-McKee on the graph of SUPPORTED loop edges -- (a, b) is supported
+ * when some edge joins {a-1, a, a+1} x {b-1, b, b+1} other than itself, which keeps the mesh of true revisits and drops
+ * isolated random loops; the last (short) segment stays last.  Pure host logic.                                     */
+int pgo_pose_order(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int32_t segment,
+                   int32_t* perm);                                                /* [host] */
 /* halo of that plan: send_rows[s] = how many of rank's rows peer s references, recv_rows[s] = how many of
  * peer s's rows rank references (arrays of `world` entries; the own-rank entries are 0).  Pure host logic.  */
 int pgo_shard_halo(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,

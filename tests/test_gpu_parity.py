@@ -478,3 +478,33 @@ def test_cli_method2_writes_switches(pgo, tmp_path):
     vals = np.array([float(l.split()[4]) for l in lines[1229:1229 + 256]])
     ref_sw = np.load(os.path.join(GOLDEN, "lm_INTEL_out50_m2_switches.npy"))
     assert np.abs(vals - ref_sw[1227:1227 + 256]).max() < 1e-5  # default stream formatting: 6 significant digits
+
+
+@pytest.mark.parametrize("name,n_out,method", [("INTEL", 50, 1), ("M3500", 0, 2)])
+def test_internal_pose_ordering_is_transparent(pgo, oracle, name, n_out, method):
+    """pose_ordering = 1 renumbers the poses inside the solver only: every output stays in the caller's numbering"""
+    g = load(pgo, name, n_out)
+    og = oracle_graph(oracle, g)
+    a = pgo.Solver(g, pgo.Options(method=method, pose_ordering=0, max_iters=6, pcg_max_iters=200000))
+    b = pgo.Solver(g, pgo.Options(method=method, pose_ordering=1, max_iters=6, pcg_max_iters=200000))
+    ca, ra, Ja = a.evaluate()
+    cb, rb, Jb = b.evaluate()
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(Ja, Jb)
+    assert ca == pytest.approx(cb, rel=1e-13)
+    if method != 2:
+        ga, ha = a.normal_eq()
+        gb, hb = b.normal_eq()
+        np.testing.assert_allclose(gb, ga, atol=1e-12)
+        np.testing.assert_allclose(hb, ha, atol=1e-11)
+        x = np.random.default_rng(5).standard_normal(3 * g.n_poses)
+        np.testing.assert_allclose(b.spmv(x), a.spmv(x), atol=1e-10)
+    rng = np.random.default_rng(6)
+    xp = np.array(g.poses) + 0.01 * rng.standard_normal((g.n_poses, 3))
+    assert a.evaluate(xp, want_r=False, want_J=False)[0] == pytest.approx(b.evaluate(xp, want_r=False, want_J=False)[0], rel=1e-13)
+    sa, sb = a.solve(), b.solve()
+    assert sa.final_cost == pytest.approx(sb.final_cost, rel=1e-8)
+    assert np.abs(a.poses() - b.poses()).max() < 2e-6
+    if method == 2:
+        assert np.abs(a.switches() - b.switches()).max() < 1e-7
+    a.close(); b.close()

@@ -21,7 +21,7 @@ import numpy as np
 from . import _build
 
 __all__ = ["PgoError", "Options", "Summary", "IterRecord", "ReadG2O", "Graph", "Solver", "Comm", "lib", "build",
-           "synth_manhattan", "shard_plan", "shard_halo", "KernelStats", "EXPORTS", "TERMINATION"]
+           "synth_manhattan", "shard_plan", "shard_halo", "pose_order", "KernelStats", "EXPORTS", "TERMINATION"]
 
 EDGE_ODOMETRY, EDGE_CLOSURE, EDGE_BOGUS = 0, 1, 2
 TERMINATION = {1: "CONVERGENCE_FTOL", 2: "CONVERGENCE_GTOL", 3: "CONVERGENCE_PTOL", 4: "NO_CONVERGENCE",
@@ -40,7 +40,7 @@ EXPORTS = [
     "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
     "pgo_write_switches",
     "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_debug_spmv", "pgo_debug_normal_eq",
-    "pgo_shard_plan", "pgo_shard_halo",
+    "pgo_shard_plan", "pgo_shard_halo", "pgo_pose_order",
 ]
 
 
@@ -59,7 +59,7 @@ class Options(C.Structure):
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
                 ("max_lm_diagonal", C.c_double), ("pcg_rtol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("pcg_check_every", C.c_int32), ("verbose", C.c_int32),
-                ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("sc_prior_lambda", C.c_double), ("reserved", C.c_int32 * 4)]
+                ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("sc_prior_lambda", C.c_double), ("pose_ordering", C.c_int32), ("reserved", C.c_int32 * 3)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -171,6 +171,7 @@ def lib():
     L.pgo_shard_plan.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
     L.pgo_shard_halo.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int64)]
+    L.pgo_pose_order.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int32, ip]
     _LIB = L
     return L
 
@@ -327,6 +328,15 @@ def shard_plan(n_poses, ia, ib, world, rank, row_align=1):
     _check(lib().pgo_shard_plan(n_poses, len(ia), _ip(ia), _ip(ib), world, rank, row_align, C.byref(lo), C.byref(hi),
                                 C.byref(nl), C.byref(nc)))
     return lo.value, hi.value, nl.value, nc.value
+
+
+def pose_order(n_poses, ia, ib, segment=64):
+    """perm[i] = internal position of pose i under the locality ordering (pgo_pose_order)"""
+    ia = np.ascontiguousarray(ia, np.int32)
+    ib = np.ascontiguousarray(ib, np.int32)
+    perm = np.zeros(n_poses, np.int32)
+    _check(lib().pgo_pose_order(n_poses, len(ia), _ip(ia), _ip(ib), segment, _ip(perm)))
+    return perm
 
 
 def shard_halo(n_poses, ia, ib, world, rank, row_align=1):

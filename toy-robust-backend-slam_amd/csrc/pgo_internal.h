@@ -80,6 +80,11 @@ int build_shard_structure(int32_t n_poses, int32_t n_edges, const int32_t* ia, c
                           const double* meas, const uint8_t* kind, int method, int world, int rank, int row_align,
                           ShardStructure* out);
 
+// locality ordering (structure.cpp): perm[i] = new position of pose i
+int compute_pose_order(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int32_t segment,
+                       std::vector<int32_t>* perm);
+constexpr int ORDER_SEGMENT = 64;
+
 // poses per block of the block-Jacobi preconditioner for an option value (0 = auto)
 inline int resolve_block_poses(int opt_value, int32_t n_poses) {
   int b = opt_value;

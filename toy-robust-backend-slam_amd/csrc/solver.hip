@@ -99,6 +99,19 @@ struct pgo_handle {
          *sw_gs = nullptr, *sw_den = nullptr, *sw_hss = nullptr, *diag_full = nullptr, *gs_full = nullptr;
   double sw_norm2 = 0.0, xnorm2_pose = 0.0;
   bool sw_fresh = false;  // elimination coefficients / reduced system match the current point AND radius
+  // internal pose numbering (opt.pose_ordering): perm[i] = internal position of the caller's pose i; empty = identity
+  std::vector<int32_t> perm;
+  int fixed_internal = -1;  // opt.fixed_pose in the internal numbering
+  // host <-> device pose-vector helpers honouring the permutation (n_cols doubles per pose)
+  void to_internal(const double* in, std::vector<double>* out, int n_cols) const {
+    const int64_t N = S.n_poses;
+    out->resize((size_t)N * n_cols);
+    for (int64_t i = 0; i < N; ++i) memcpy(&(*out)[(size_t)perm[i] * n_cols], in + i * n_cols, (size_t)n_cols * sizeof(double));
+  }
+  void to_caller(const std::vector<double>& in, double* out, int n_cols) const {
+    const int64_t N = S.n_poses;
+    for (int64_t i = 0; i < N; ++i) memcpy(out + i * n_cols, &in[(size_t)perm[i] * n_cols], (size_t)n_cols * sizeof(double));
+  }
   // captured slice of PCG iterations (world == 1)
   hipGraphExec_t cg_graph_exec = nullptr;
   int cg_graph_len = 0;
@@ -343,6 +356,27 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   const char* fc = getenv("PGO_FORCE_COLLECTIVES");
   force_collectives = fc && fc[0] == '1';
   grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
+  // internal pose numbering
+  const bool reorder = opt.pose_ordering == 1 || (opt.pose_ordering < 0 && world > 1);
+  std::vector<int32_t> ia_p, ib_p;
+  std::vector<double> poses_p;
+  fixed_internal = opt.fixed_pose;
+  if (reorder) {
+    PGOC(pgo::compute_pose_order(N, E, ia, ib, pgo::ORDER_SEGMENT, &perm));
+    ia_p.resize(E);
+    ib_p.resize(E);
+    for (int32_t e = 0; e < E; ++e) {
+      if (ia[e] < 0 || ia[e] >= N || ib[e] < 0 || ib[e] >= N) return fail(PGO_ERR_INVALID_ARG, "edge endpoint out of range");
+      ia_p[e] = perm[ia[e]];
+      ib_p[e] = perm[ib[e]];
+    }
+    poses_p.resize((size_t)3 * N);
+    for (int64_t i = 0; i < N; ++i) memcpy(&poses_p[(size_t)3 * perm[i]], poses_h + 3 * i, 3 * sizeof(double));
+    ia = ia_p.data();
+    ib = ib_p.data();
+    poses_h = poses_p.data();
+    if (fixed_internal >= 0) fixed_internal = perm[fixed_internal];
+  }
   PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, grp_B, &S));
   HIPC(hipSetDevice(device));
   HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -400,6 +434,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   for (int k = 0; k < N_PART; ++k) PGOC(dalloc(&part[k], part_cap));
 
   HIPC(hipMemcpyAsync(poses, poses_h, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, stream));
+  PGOC(sync());  // poses_p (reordered copy) dies with this call
   PGOC(upload(e_ia, S.ia));
   PGOC(upload(e_ib, S.ib));
   PGOC(upload(e_mx, S.mx));
@@ -507,7 +542,7 @@ int pgo_handle::lm_begin() {
   recs.clear();
   const double t_begin = wall_s();
   t_total = 0;
-  const int fixed = opt.fixed_pose;
+  const int fixed = fixed_internal;
   if (has_sw) {  // switches start at 1.0 (main.cpp:117,139); nothing eliminated yet
     std::vector<double> ones((size_t)std::max(1, S.n_edges_local), 1.0);
     HIPC(hipMemcpyAsync(sw, ones.data(), (size_t)S.n_edges_local * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -674,7 +709,7 @@ int pgo_handle::lm_iteration(bool* stop) {
 
   // LM diagonal + preconditioner, then the linear solve
   double t0 = wall_s();
-  hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, (const double*)diag_full, S.n_loc, S.lo, opt.fixed_pose, radius,
+  hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, (const double*)diag_full, S.n_loc, S.lo, fixed_internal, radius,
                      opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv);
   PGOC(check_launch("k_prepare"));
   if (grp_B > 1) {
@@ -885,6 +920,7 @@ void pgo_options_default(pgo_options* o) {
   o->verbose = 0;
   o->use_graphs = 1;
   o->sc_prior_lambda = 1.0;
+  o->pose_ordering = -1;
 }
 
 int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
@@ -919,6 +955,11 @@ void pgo_destroy(pgo_t* h) { delete h; }
 int pgo_set_poses(pgo_t* h, const double* poses) {
   if (!h || !poses) return fail(PGO_ERR_INVALID_ARG, "pgo_set_poses: null");
   HIPC(hipSetDevice(h->device));
+  std::vector<double> tmp;
+  if (!h->perm.empty()) {
+    h->to_internal(poses, &tmp, 3);
+    poses = tmp.data();
+  }
   HIPC(hipMemcpyAsync(h->poses, poses, (size_t)3 * h->S.n_poses * sizeof(double), hipMemcpyHostToDevice, h->stream));
   h->lin_valid = false;
   h->lm_active = false;
@@ -928,8 +969,15 @@ int pgo_set_poses(pgo_t* h, const double* poses) {
 int pgo_get_poses(pgo_t* h, double* out) {
   if (!h || !out) return fail(PGO_ERR_INVALID_ARG, "pgo_get_poses: null");
   HIPC(hipSetDevice(h->device));
-  HIPC(hipMemcpyAsync(out, h->poses, (size_t)3 * h->S.n_poses * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  return h->sync();
+  if (h->perm.empty()) {
+    HIPC(hipMemcpyAsync(out, h->poses, (size_t)3 * h->S.n_poses * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return h->sync();
+  }
+  std::vector<double> tmp((size_t)3 * h->S.n_poses);
+  HIPC(hipMemcpyAsync(tmp.data(), h->poses, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PGOC(h->sync());
+  h->to_caller(tmp, out, 3);
+  return PGO_OK;
 }
 
 int pgo_get_switches(pgo_t* h, double* switches, double* js_out) {
@@ -963,7 +1011,14 @@ int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss, double* cost
   if (want_jac && h->comm && h->comm->world > 1) return fail(PGO_ERR_UNSUPPORTED, "pgo_eval: r/J outputs need world == 1");
   const double* x = h->poses;
   if (poses_or_null) {
-    HIPC(hipMemcpyAsync(h->cand, poses_or_null, (size_t)3 * h->S.n_poses * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    std::vector<double> tmp;
+    const double* src = poses_or_null;
+    if (!h->perm.empty()) {
+      h->to_internal(poses_or_null, &tmp, 3);
+      src = tmp.data();
+    }
+    HIPC(hipMemcpyAsync(h->cand, src, (size_t)3 * h->S.n_poses * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    PGOC(h->sync());  // tmp dies with this scope
     x = h->cand;
   }
   if (want_jac) {
@@ -1041,23 +1096,30 @@ int pgo_debug_normal_eq(pgo_t* h, double* g_out, double* hdiag_out) {
   HIPC(hipSetDevice(h->device));
   h->lm_active = false;
   hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(h->g_rows), dim3(dev::WG), 0, h->stream, h->hd, h->S.n_loc, h->S.lo,
-                     h->opt.fixed_pose, 0, h->scale);
+                     h->fixed_internal, 0, h->scale);
   PGOC(h->check_launch("k_jacobi_scale"));
   int st = h->linearize(false);
   h->lin_valid = false;
   PGOC(st);
   const int64_t N = h->S.n_loc;
-  if (g_out) HIPC(hipMemcpyAsync(g_out, h->gs, (size_t)3 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> g_tmp;
+  if (g_out) {
+    g_tmp.resize((size_t)3 * N);
+    HIPC(hipMemcpyAsync(g_tmp.data(), h->gs, g_tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
   std::vector<double> planes;
   if (hdiag_out) {
     planes.resize((size_t)6 * N);
     HIPC(hipMemcpyAsync(planes.data(), h->hd, planes.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
   PGOC(h->sync());
+  auto internal = [&](int64_t i) { return h->perm.empty() ? i : (int64_t)h->perm[i]; };
+  if (g_out)
+    for (int64_t i = 0; i < N; ++i) memcpy(g_out + 3 * i, &g_tmp[(size_t)3 * internal(i)], 3 * sizeof(double));
   if (hdiag_out) {
     static const int map9[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
     for (int64_t i = 0; i < N; ++i)
-      for (int c = 0; c < 9; ++c) hdiag_out[9 * i + c] = planes[(size_t)map9[c] * N + i];
+      for (int c = 0; c < 9; ++c) hdiag_out[9 * i + c] = planes[(size_t)map9[c] * N + internal(i)];
   }
   return PGO_OK;
 }
@@ -1067,11 +1129,24 @@ int pgo_debug_spmv(pgo_t* h, const double* x, double* yout) {
   if (h->comm && h->comm->world > 1) return fail(PGO_ERR_UNSUPPORTED, "world == 1 only");
   HIPC(hipSetDevice(h->device));
   const int64_t N = h->S.n_poses;
-  HIPC(hipMemcpyAsync(h->y, x, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  std::vector<double> tmp;
+  const double* src = x;
+  if (!h->perm.empty()) {
+    h->to_internal(x, &tmp, 3);
+    src = tmp.data();
+  }
+  HIPC(hipMemcpyAsync(h->y, src, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(dev::k_scatter_owned, dim3(h->g_flat), dim3(dev::WG), 0, h->stream, h->S.n_loc, h->S.lo, h->y, h->p_full);
   PGOC(h->spmv_enqueue(h->p_full, h->ap, h->part[0], 0, nullptr));
-  HIPC(hipMemcpyAsync(yout, h->ap, (size_t)3 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  return h->sync();
+  if (h->perm.empty()) {
+    HIPC(hipMemcpyAsync(yout, h->ap, (size_t)3 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return h->sync();
+  }
+  std::vector<double> ytmp((size_t)3 * N);
+  HIPC(hipMemcpyAsync(ytmp.data(), h->ap, ytmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PGOC(h->sync());
+  h->to_caller(ytmp, yout, 3);
+  return PGO_OK;
 }
 
 static int time_launches(pgo_handle* h, int reps, const std::function<void()>& launch, double* ms_avg) {

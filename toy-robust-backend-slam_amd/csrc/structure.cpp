@@ -12,10 +12,92 @@
 //   is counted on the rank that owns its first endpoint Edge::a.
 #include <algorithm>
 #include <numeric>
+#include <queue>
+#include <unordered_set>
 
 #include "pgo_internal.h"
 
 namespace pgo {
+
+// Locality ordering of the poses (see pgo_pose_order in pgo.h).
+int compute_pose_order(int32_t N, int32_t E, const int32_t* ia, const int32_t* ib, int32_t L, std::vector<int32_t>* perm) {
+  if (N <= 0 || E < 0 || L < 1) return fail(PGO_ERR_INVALID_ARG, "compute_pose_order: bad sizes");
+  perm->resize(N);
+  const int32_t n_full = N / L;  // full segments; a short tail segment keeps its place at the end
+  if (n_full < 3) {
+    std::iota(perm->begin(), perm->end(), 0);
+    return PGO_OK;
+  }
+  // supported loop edges -> edges of the segment graph
+  std::unordered_set<int64_t> pairs;
+  pairs.reserve((size_t)E * 2);
+  auto key = [N](int64_t a, int64_t b) { return a < b ? a * N + b : b * N + a; };
+  for (int32_t e = 0; e < E; ++e) pairs.insert(key(ia[e], ib[e]));
+  std::vector<std::pair<int32_t, int32_t>> seg_edges;
+  for (int32_t e = 0; e < E; ++e) {
+    const int64_t a = ia[e], b = ib[e];
+    const int32_t sa = (int32_t)(a / L), sb = (int32_t)(b / L);
+    if (sa == sb || sa >= n_full || sb >= n_full) continue;
+    bool ok = std::llabs(a - b) <= 1;
+    for (int da = -1; da <= 1 && !ok; ++da)
+      for (int db = -1; db <= 1 && !ok; ++db) {
+        if (da == 0 && db == 0) continue;
+        const int64_t x = a + da, y = b + db;
+        if (x < 0 || y < 0 || x >= N || y >= N || x == y) continue;
+        ok = pairs.count(key(x, y)) != 0;
+      }
+    if (ok) seg_edges.emplace_back(std::min(sa, sb), std::max(sa, sb));
+  }
+  std::sort(seg_edges.begin(), seg_edges.end());
+  seg_edges.erase(std::unique(seg_edges.begin(), seg_edges.end()), seg_edges.end());
+  std::vector<int32_t> ptr((size_t)n_full + 1, 0), adj(seg_edges.size() * 2);
+  for (auto& pr : seg_edges) {
+    ptr[pr.first + 1]++;
+    ptr[pr.second + 1]++;
+  }
+  for (int32_t i = 0; i < n_full; ++i) ptr[i + 1] += ptr[i];
+  {
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (auto& pr : seg_edges) {
+      adj[fill[pr.first]++] = pr.second;
+      adj[fill[pr.second]++] = pr.first;
+    }
+  }
+  auto deg = [&](int32_t v) { return ptr[v + 1] - ptr[v]; };
+  // Cuthill-McKee per connected component, components entered at their lowest-degree segment in index order
+  std::vector<int32_t> order;
+  order.reserve(n_full);
+  std::vector<char> seen(n_full, 0);
+  std::vector<int32_t> by_deg(n_full);
+  std::iota(by_deg.begin(), by_deg.end(), 0);
+  std::stable_sort(by_deg.begin(), by_deg.end(), [&](int32_t x, int32_t y) { return deg(x) < deg(y); });
+  std::vector<int32_t> nb;
+  for (int32_t start : by_deg) {
+    if (seen[start]) continue;
+    size_t head = order.size();
+    order.push_back(start);
+    seen[start] = 1;
+    while (head < order.size()) {
+      const int32_t v = order[head++];
+      nb.clear();
+      for (int32_t q = ptr[v]; q < ptr[v + 1]; ++q)
+        if (!seen[adj[q]]) {
+          seen[adj[q]] = 1;
+          nb.push_back(adj[q]);
+        }
+      std::sort(nb.begin(), nb.end(), [&](int32_t x, int32_t y) { return deg(x) != deg(y) ? deg(x) < deg(y) : x < y; });
+      order.insert(order.end(), nb.begin(), nb.end());
+    }
+  }
+  std::reverse(order.begin(), order.end());
+  std::vector<int32_t> start_of(n_full);
+  for (int32_t k = 0; k < n_full; ++k) start_of[order[k]] = k * L;
+  for (int32_t i = 0; i < N; ++i) {
+    const int32_t sgm = i / L;
+    (*perm)[i] = sgm < n_full ? start_of[sgm] + (i - sgm * L) : i;
+  }
+  return PGO_OK;
+}
 
 // Halo of the gather vector for world > 1 (needs the WHOLE edge list: what the peers reference of this
 // rank's rows).  Both lists are grouped by peer and sorted by global row, so that rank s's send list to r is
@@ -218,5 +300,19 @@ extern "C" int pgo_shard_halo(int32_t n_poses, int32_t n_edges, const int32_t* i
     send_rows[s] = S.halo_send_off[s + 1] - S.halo_send_off[s];
     recv_rows[s] = S.halo_recv_off[s + 1] - S.halo_recv_off[s];
   }
+  return PGO_OK;
+}
+
+extern "C" int pgo_pose_order(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int32_t segment,
+                              int32_t* perm) {
+  if (n_poses <= 0 || n_edges < 0 || segment < 1 || !perm || (n_edges && (!ia || !ib)))
+    return pgo::fail(PGO_ERR_INVALID_ARG, "pgo_pose_order: bad argument");
+  for (int32_t e = 0; e < n_edges; ++e)
+    if (ia[e] < 0 || ia[e] >= n_poses || ib[e] < 0 || ib[e] >= n_poses)
+      return pgo::fail(PGO_ERR_INVALID_ARG, "pgo_pose_order: endpoint out of range");
+  std::vector<int32_t> p;
+  int st = pgo::compute_pose_order(n_poses, n_edges, ia, ib, segment, &p);
+  if (st != PGO_OK) return st;
+  std::copy(p.begin(), p.end(), perm);
   return PGO_OK;
 }
