@@ -178,7 +178,7 @@ def main():
                         "candidate": summ.seconds_candidate},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        if world == 1 and args.poses == 1000000 and os.path.exists(pmc):  # HBM bytes per launch of the whole-matrix k_spmv, from the committed rocprofv3 --pmc passes
             try:
                 out["roofline"]["traffic"] = json.load(open(pmc)).get("k_spmv_bytes_per_launch")
             except Exception:

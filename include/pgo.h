@@ -159,7 +159,15 @@ typedef struct pgo_options {
                                   0 = the caller's, 1 = locality ordering (pgo_pose_order: segments of 64 consecutive
                                   poses reordered by reverse Cuthill-McKee on the loop edges that a neighbouring edge
                                   supports), -1 (default) = 1 when world > 1 (it shrinks every rank's halo), else 0  */
-  int32_t reserved[3];
+  int32_t info_weighting;      /* 0 (default) = the reference's objective: the information entries of an edge are parsed
+                                  but unused.  1 = optional mode: every residual is whitened by
+                                  its information matrix, e_w = L' e with Omega = L L', so |e_w|^2 = e' Omega e (the chi2
+                                  of compute_edge_mahalanobis, src/layer_manager.cpp:230-282); Huber then acts on chi2 and
+                                  METHOD 1 uses the chi2 form of DCS, s = min(1, 2 phi / (phi + chi2)), e = s e_w
+                                  (differentiated through s, as the reference differentiates through psi).  Needs the
+                                  information matrices (pgo_create_weighted / pgo_create_from_graph), all positive
+                                  definite; METHOD 2: PGO_ERR_UNSUPPORTED                                            */
+  int32_t reserved[2];
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */
@@ -223,6 +231,13 @@ int pgo_create(pgo_t** h, int32_t n_poses, const double* poses_xyt,
                int32_t n_edges, const int32_t* ia, const int32_t* ib,
                const double* meas_xyt, const uint8_t* kind,
                const pgo_options* opt, pgo_comm* comm_or_null, int device);       /* [gpu] */
+/* same, with the edges' information matrices: info6 = E x 6 (I11 I12 I13 I22 I23 I33, the reference's Edge fields,
+ * include/graph.h:41-47) or NULL.  They are used by opt->info_weighting = 1 and by pgo_edge_chi2 only.                */
+int pgo_create_weighted(pgo_t** h, int32_t n_poses, const double* poses_xyt,
+                        int32_t n_edges, const int32_t* ia, const int32_t* ib,
+                        const double* meas_xyt, const double* info6_or_null, const uint8_t* kind,
+                        const pgo_options* opt, pgo_comm* comm_or_null, int device); /* [gpu] */
+/* passes the graph's information matrices along */
 int pgo_create_from_graph(pgo_t** h, const pgo_graph* g, const pgo_options* opt,
                           pgo_comm* comm_or_null, int device);                    /* [gpu] */
 void pgo_destroy(pgo_t* h);
@@ -235,6 +250,13 @@ void pgo_destroy(pgo_t* h);
  * r/J outputs need world == 1.                                                  */
 int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss,
              double* cost, double* r_or_null, double* J_or_null);                 /* [gpu] */
+
+/* compute_edge_mahalanobis (src/layer_manager.cpp:230-282; the layer managers' edge gate) for every edge at once:
+ * chi2[e] = r' Omega r of the PLAIN residual r = (ex, ey, asin(clamp(sin delta, -1, 1))), clamped at 0, in the
+ * caller's edge order, at the handle's current poses or at poses_or_null.  Independent of opt->method and
+ * opt->info_weighting; any symmetric Omega.  Needs a handle created with information matrices.
+ * world > 1: every rank gets the whole vector (one all-reduce).                                                */
+int pgo_edge_chi2(pgo_t* h, const double* poses_or_null, double* chi2_out /* E */);   /* [gpu] */
 
 /* ceres::Solve (main.cpp:163): LM from the current poses for opt.max_iters.      */
 int pgo_solve(pgo_t* h, pgo_summary* s);                                          /* [gpu] */

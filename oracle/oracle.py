@@ -69,18 +69,22 @@ def lib():
         L.pgo_oracle_edge.restype = None
         L.pgo_oracle_huber.argtypes = [C.c_double, C.c_double, dp]
         L.pgo_oracle_huber.restype = None
-        L.pgo_oracle_eval.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, C.c_int, C.c_double, C.c_double,
-                                      C.c_int, dp, dp, C.c_int]
-        L.pgo_oracle_eval.restype = C.c_double
+        L.pgo_oracle_edge_w.argtypes = [dp, dp, dp, dp, C.c_int, C.c_double, dp, dp]
+        L.pgo_oracle_edge_w.restype = None
+        L.pgo_oracle_edge_chi2.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, dp]
+        L.pgo_oracle_edge_chi2.restype = None
+        L.pgo_oracle_eval_w.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, bp, C.c_int, C.c_double, C.c_double,
+                                        C.c_int, dp, dp, C.c_int]
+        L.pgo_oracle_eval_w.restype = C.c_double
         L.pgo_oracle_eval_sc.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, dp, C.c_double, C.c_double, C.c_int, dp, dp,
                                          dp, dp, C.c_int]
         L.pgo_oracle_eval_sc.restype = C.c_double
-        L.pgo_oracle_lm_pcg.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, C.POINTER(_Opts), C.POINTER(_Iter),
-                                        C.c_int, C.POINTER(C.c_int), C.POINTER(_Summary)]
-        L.pgo_oracle_lm_pcg.restype = C.c_int
-        L.pgo_oracle_normal_eq.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, C.c_int, C.c_double, C.c_double,
-                                           C.c_int, dp, dp, dp, dp, dp, C.c_int]
-        L.pgo_oracle_normal_eq.restype = C.c_int
+        L.pgo_oracle_lm_pcg_w.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, bp, C.POINTER(_Opts), C.POINTER(_Iter),
+                                          C.c_int, C.POINTER(C.c_int), C.POINTER(_Summary)]
+        L.pgo_oracle_lm_pcg_w.restype = C.c_int
+        L.pgo_oracle_normal_eq_w.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, bp, C.c_int, C.c_double, C.c_double,
+                                             C.c_int, dp, dp, dp, dp, dp, C.c_int]
+        L.pgo_oracle_normal_eq_w.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -213,14 +217,33 @@ def add_random_C(g: Graph, count: int, seed: int) -> Graph:
 
 
 # ---------------------------------------------------------------- evaluation
-def edge(P1, P2, meas, dcs: bool, phi: float = 0.5, jac: bool = True):
+def edge(P1, P2, meas, dcs: bool, phi: float = 0.5, jac: bool = True, info=None):
+    """one residual block; info = (I11, I12, I13, I22, I23, I33) switches to the whitened / chi2-DCS form"""
     P1 = np.ascontiguousarray(P1, np.float64)
     P2 = np.ascontiguousarray(P2, np.float64)
     m = np.ascontiguousarray(meas, np.float64)
     e = np.zeros(3)
     J = np.zeros(18) if jac else None
-    lib().pgo_oracle_edge(_dp(P1), _dp(P2), _dp(m), int(dcs), phi, _dp(e), _dp(J))
+    if info is None:
+        lib().pgo_oracle_edge(_dp(P1), _dp(P2), _dp(m), int(dcs), phi, _dp(e), _dp(J))
+    else:
+        w = np.ascontiguousarray(info, np.float64)
+        lib().pgo_oracle_edge_w(_dp(P1), _dp(P2), _dp(m), _dp(w), int(dcs), phi, _dp(e), _dp(J))
     return (e, J.reshape(3, 6)) if jac else e
+
+
+def _info(g, info_weighting):
+    return np.ascontiguousarray(g.info, np.float64) if info_weighting else None
+
+
+def edge_chi2(g: "Graph", poses=None):
+    """compute_edge_mahalanobis (src/layer_manager.cpp:230-282) for every edge: r' Omega r of the plain residual"""
+    poses = np.ascontiguousarray(g.poses if poses is None else poses, np.float64)
+    ia, ib = np.ascontiguousarray(g.ia, np.int32), np.ascontiguousarray(g.ib, np.int32)
+    meas, w = np.ascontiguousarray(g.meas, np.float64), np.ascontiguousarray(g.info, np.float64)
+    out = np.zeros(g.n_edges)
+    lib().pgo_oracle_edge_chi2(g.n_poses, _dp(poses), g.n_edges, _ip(ia), _ip(ib), _dp(meas), _dp(w), _dp(out))
+    return out
 
 
 def huber(s: float, delta: float = 0.01):
@@ -230,15 +253,16 @@ def huber(s: float, delta: float = 0.01):
 
 
 def evaluate(g: Graph, poses=None, method: int = 1, phi: float = 0.5, delta: float = 0.01, apply_loss: bool = True,
-             want_r: bool = True, want_J: bool = True, threads: int = 1):
+             want_r: bool = True, want_J: bool = True, threads: int = 1, info_weighting: bool = False):
     poses = np.ascontiguousarray(g.poses if poses is None else poses, np.float64)
     E = g.n_edges
+    w = _info(g, info_weighting)
     r = np.zeros((E, 3)) if want_r else None
     J = np.zeros((E, 18)) if want_J else None
     ia, ib = np.ascontiguousarray(g.ia, np.int32), np.ascontiguousarray(g.ib, np.int32)
     meas, kind = np.ascontiguousarray(g.meas, np.float64), np.ascontiguousarray(g.kind, np.uint8)
-    cost = lib().pgo_oracle_eval(g.n_poses, _dp(poses), E, _ip(ia), _ip(ib), _dp(meas), _bp(kind), method, phi, delta,
-                                 int(apply_loss), _dp(r), _dp(J), threads)
+    cost = lib().pgo_oracle_eval_w(g.n_poses, _dp(poses), E, _ip(ia), _ip(ib), _dp(meas), _dp(w), _bp(kind), method, phi,
+                                   delta, int(apply_loss), _dp(r), _dp(J), threads)
     return cost, r, J
 
 
@@ -257,7 +281,8 @@ def evaluate_sc(g: Graph, poses=None, switches=None, lam: float = 1.0, delta: fl
     return cost, r, J, Js, q
 
 
-def normal_eq(g: Graph, poses=None, method=1, phi=0.5, delta=0.01, fixed_pose=0, s=None, x=None, threads=1):
+def normal_eq(g: Graph, poses=None, method=1, phi=0.5, delta=0.01, fixed_pose=0, s=None, x=None, threads=1,
+              info_weighting=False):
     """(gradient S J'r, diagonal blocks of (JS)'(JS), optional y = (JS)'(JS) x) at `poses`."""
     poses = np.ascontiguousarray(g.poses if poses is None else poses, np.float64)
     N = g.n_poses
@@ -267,8 +292,9 @@ def normal_eq(g: Graph, poses=None, method=1, phi=0.5, delta=0.01, fixed_pose=0,
     ss = np.ascontiguousarray(s, np.float64) if s is not None else None
     ia, ib = np.ascontiguousarray(g.ia, np.int32), np.ascontiguousarray(g.ib, np.int32)
     meas, kind = np.ascontiguousarray(g.meas, np.float64), np.ascontiguousarray(g.kind, np.uint8)
-    lib().pgo_oracle_normal_eq(N, _dp(poses), g.n_edges, _ip(ia), _ip(ib), _dp(meas), _bp(kind), method, phi, delta,
-                               fixed_pose, _dp(ss), _dp(gout), _dp(hd), _dp(xs), _dp(y), threads)
+    w = _info(g, info_weighting)
+    lib().pgo_oracle_normal_eq_w(N, _dp(poses), g.n_edges, _ip(ia), _ip(ib), _dp(meas), _dp(w), _bp(kind), method, phi,
+                                 delta, fixed_pose, _dp(ss), _dp(gout), _dp(hd), _dp(xs), _dp(y), threads)
     return gout, hd, y
 
 
@@ -295,6 +321,7 @@ class Options:
     threads: int = 1
     verbose: int = 0
     pcg_block_poses: int = 1   # lm_pcg only: poses per block-Jacobi block
+    info_weighting: int = 0    # 1: whitened residuals + chi2 DCS (optional mode, see pgo_oracle.c edge_functor_jet)
 
 
 @dataclass
@@ -339,7 +366,8 @@ def lm_direct(g: Graph, opt: Options = Options()) -> Result:
         return A[:, free_idx].tocsc()
 
     def ev(p, with_j):
-        return evaluate(g, p, opt.method, opt.phi, opt.huber_delta, True, with_j, with_j, opt.threads)
+        return evaluate(g, p, opt.method, opt.phi, opt.huber_delta, True, with_j, with_j, opt.threads,
+                        bool(opt.info_weighting))
 
     t_start = time.perf_counter()
     tm = dict(eval=0.0, linear=0.0, candidate=0.0)
@@ -475,8 +503,9 @@ def lm_pcg(g: Graph, opt: Options = Options()) -> Result:
     x = np.array(g.poses, np.float64, copy=True)
     ia, ib = np.ascontiguousarray(g.ia, np.int32), np.ascontiguousarray(g.ib, np.int32)
     meas, kind = np.ascontiguousarray(g.meas, np.float64), np.ascontiguousarray(g.kind, np.uint8)
-    lib().pgo_oracle_lm_pcg(g.n_poses, _dp(x), g.n_edges, _ip(ia), _ip(ib), _dp(meas), _bp(kind), C.byref(o), recs, cap,
-                            C.byref(nrec), C.byref(summ))
+    w = _info(g, opt.info_weighting)
+    lib().pgo_oracle_lm_pcg_w(g.n_poses, _dp(x), g.n_edges, _ip(ia), _ip(ib), _dp(meas), _dp(w), _bp(kind), C.byref(o), recs,
+                              cap, C.byref(nrec), C.byref(summ))
     out = Result(x, summ.termination, summ.iterations, summ.successful_steps, summ.initial_cost, summ.final_cost)
     out.total_pcg_iters = summ.total_pcg_iters
     out.records = [{f[0]: getattr(recs[i], f[0]) for f in _Iter._fields_ if f[0] != "_pad"} for i in range(nrec.value)]

@@ -163,8 +163,29 @@ static jmat3 jmat_inverse(const jmat3* A) {
 
 /* One residual block with Jacobian.  P1,P2: poses; m: (dx,dy,dtheta);
  * e[3]; J[18] = row-major 3x6 = [d e / d P1 | d e / d P2].                    */
-static void edge_functor_jet(const double* P1, const double* P2, const double* m, int dcs, double phi, double* e,
-                             double* J) {
+/* Cholesky factor of the information matrix Omega = L L' (info6 = I11 I12 I13 I22 I23 I33, the reference's Edge
+ * fields, include/graph.h:41-47).  Returns 0 when Omega is not positive definite.                              */
+static int info_cholesky(const double* w, double L[6] /* L00 L10 L11 L20 L21 L22 */) {
+  if (!(w[0] > 0.0)) return 0;
+  L[0] = sqrt(w[0]);
+  L[1] = w[1] / L[0];
+  L[3] = w[2] / L[0];
+  double d1 = w[3] - L[1] * L[1];
+  if (!(d1 > 0.0)) return 0;
+  L[2] = sqrt(d1);
+  L[4] = (w[4] - L[3] * L[1]) / L[2];
+  double d2 = w[5] - L[3] * L[3] - L[4] * L[4];
+  if (!(d2 > 0.0)) return 0;
+  L[5] = sqrt(d2);
+  return 1;
+}
+
+/* info != NULL (optional mode, not on the reference's METHOD 0/1 path where the information entries are parsed but
+ * unused): the residual is whitened, e_w = L' e_plain with Omega = L L', so that |e_w|^2 = e' Omega e -- the quantity
+ * compute_edge_mahalanobis returns (src/layer_manager.cpp:230-282) -- and DCS takes its chi2 form
+ * s = min(1, 2 phi / (phi + chi2)), e = s e_w (Agarwal et al. 2013; docs/code_Ex.png of the reference).          */
+static void edge_functor_jet(const double* P1, const double* P2, const double* m, const double* info, int dcs,
+                             double phi, double* e, double* J) {
   jmat3 wTa = jmat_se2(jvar(P1[0], 0), jvar(P1[1], 1), jvar(P1[2], 2));
   jmat3 wTb = jmat_se2(jvar(P2[0], 3), jvar(P2[1], 4), jvar(P2[2], 5));
   jmat3 aTb = jmat_se2(jc(m[0]), jc(m[1]), jc(m[2])); /* ctor :4-25 builds it in double, :80-83 casts */
@@ -175,7 +196,32 @@ static void edge_functor_jet(const double* P1, const double* P2, const double* m
   out[0] = diff.m[0][2];
   out[1] = diff.m[1][2];
   out[2] = jasin(diff.m[1][0]);
-  if (dcs) { /* :185-193 */
+  if (info) {
+    double L[6];
+    if (!info_cholesky(info, L)) {
+      for (int i = 0; i < 3; ++i) {
+        e[i] = NAN;
+        if (J)
+          for (int k = 0; k < 6; ++k) J[6 * i + k] = NAN;
+      }
+      return;
+    }
+    jet w0 = jadd(jadd(jmul(jc(L[0]), out[0]), jmul(jc(L[1]), out[1])), jmul(jc(L[3]), out[2]));
+    jet w1 = jadd(jmul(jc(L[2]), out[1]), jmul(jc(L[4]), out[2]));
+    jet w2 = jmul(jc(L[5]), out[2]);
+    out[0] = w0;
+    out[1] = w1;
+    out[2] = w2;
+    if (dcs) {
+      jet chi2 = jadd(jadd(jmul(w0, w0), jmul(w1, w1)), jmul(w2, w2));
+      jet sc = jdiv(jmul(jc(2.0), jc(phi)), jadd(jc(phi), chi2));
+      if (sc.a < 1.0) {
+        out[0] = jmul(sc, out[0]);
+        out[1] = jmul(sc, out[1]);
+        out[2] = jmul(sc, out[2]);
+      }
+    }
+  } else if (dcs) { /* :185-193 */
     jet res = jadd(jmul(diff.m[0][2], diff.m[0][2]), jmul(diff.m[1][2], diff.m[1][2]));
     jet psi_org = jsqrt(jdiv(jmul(jc(2.0), jc(phi)), jadd(jc(phi), res)));
     /* std::min(T(1.0), psi_org): returns psi_org iff psi_org < 1 (Jet compares scalar parts) */
@@ -220,7 +266,8 @@ static void mat_mul(double A[3][3], double B[3][3], double C[3][3]) {
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) C[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
 }
-static void edge_functor_double(const double* P1, const double* P2, const double* m, int dcs, double phi, double* e) {
+static void edge_functor_double(const double* P1, const double* P2, const double* m, const double* info, int dcs,
+                                double phi, double* e) {
   double wTa[3][3], wTb[3][3], aTb[3][3], ia[3][3], im[3][3], t[3][3], diff[3][3];
   mat_se2(P1[0], P1[1], P1[2], wTa);
   mat_se2(P2[0], P2[1], P2[2], wTb);
@@ -232,7 +279,26 @@ static void edge_functor_double(const double* P1, const double* P2, const double
   e[0] = diff[0][2];
   e[1] = diff[1][2];
   e[2] = asin(diff[1][0]);
-  if (dcs) {
+  if (info) {
+    double L[6];
+    if (!info_cholesky(info, L)) {
+      e[0] = e[1] = e[2] = NAN;
+      return;
+    }
+    double w0 = L[0] * e[0] + L[1] * e[1] + L[3] * e[2], w1 = L[2] * e[1] + L[4] * e[2], w2 = L[5] * e[2];
+    e[0] = w0;
+    e[1] = w1;
+    e[2] = w2;
+    if (dcs) {
+      double chi2 = w0 * w0 + w1 * w1 + w2 * w2;
+      double sc = 2.0 * phi / (phi + chi2);
+      if (sc < 1.0) {
+        e[0] *= sc;
+        e[1] *= sc;
+        e[2] *= sc;
+      }
+    }
+  } else if (dcs) {
     double res = diff[0][2] * diff[0][2] + diff[1][2] * diff[1][2];
     double psi_org = sqrt(2.0 * phi / (phi + res));
     double psi = (psi_org < 1.0) ? psi_org : 1.0;
@@ -261,8 +327,38 @@ static void huber(double s, double a, double rho[3]) {
 /* ---------------------------------------------------------------- exports */
 void pgo_oracle_edge(const double* P1, const double* P2, const double* meas, int dcs, double phi, double* e,
                      double* J /* 18 or NULL */) {
-  if (J) edge_functor_jet(P1, P2, meas, dcs, phi, e, J);
-  else edge_functor_double(P1, P2, meas, dcs, phi, e);
+  if (J) edge_functor_jet(P1, P2, meas, NULL, dcs, phi, e, J);
+  else edge_functor_double(P1, P2, meas, NULL, dcs, phi, e);
+}
+void pgo_oracle_edge_w(const double* P1, const double* P2, const double* meas, const double* info6, int dcs,
+                       double phi, double* e, double* J /* 18 or NULL */) {
+  if (J) edge_functor_jet(P1, P2, meas, info6, dcs, phi, e, J);
+  else edge_functor_double(P1, P2, meas, info6, dcs, phi, e);
+}
+
+/* compute_edge_mahalanobis (src/layer_manager.cpp:230-282): m = r' Omega r of the PLAIN residual r = (ex, ey, etheta),
+ * etheta = asin(clamp(diff[1][0], -1, 1)), m clamped at 0; any symmetric Omega (no factorisation).              */
+void pgo_oracle_edge_chi2(int N, const double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
+                          const double* info, double* out) {
+  (void)N;
+  for (int e = 0; e < E; ++e) {
+    double wTa[3][3], wTb[3][3], aTb[3][3], iA[3][3], iM[3][3], t[3][3], diff[3][3];
+    const double *P1 = poses + 3 * (size_t)ia[e], *P2 = poses + 3 * (size_t)ib[e], *m = meas + 3 * (size_t)e;
+    const double* w = info + 6 * (size_t)e;
+    mat_se2(P1[0], P1[1], P1[2], wTa);
+    mat_se2(P2[0], P2[1], P2[2], wTb);
+    mat_se2(m[0], m[1], m[2], aTb);
+    mat_inverse(wTa, iA);
+    mat_inverse(aTb, iM);
+    mat_mul(iA, wTb, t);
+    mat_mul(iM, t, diff);
+    double ex = diff[0][2], ey = diff[1][2];
+    double sd = diff[1][0] > 1.0 ? 1.0 : (diff[1][0] < -1.0 ? -1.0 : diff[1][0]);
+    double et = asin(sd);
+    double v = ex * (w[0] * ex + w[1] * ey + w[2] * et) + ey * (w[1] * ex + w[3] * ey + w[4] * et) +
+               et * (w[2] * ex + w[4] * ey + w[5] * et);
+    out[e] = v < 0.0 ? 0.0 : v;
+  }
 }
 
 void pgo_oracle_huber(double s, double delta, double* rho3) { huber(s, delta, rho3); }
@@ -272,9 +368,9 @@ void pgo_oracle_huber(double s, double delta, double* rho3) { huber(s, delta, rh
  * sqrt(rho') (Ceres Corrector with rho'' <= 0).  delta <= 0: no loss.
  * r: E x 3 or NULL, J: E x 18 or NULL.  Returns cost = 1/2 sum rho(|e|^2).
  * Returns NAN-poisoned cost when a residual/Jacobian entry is not finite.      */
-double pgo_oracle_eval(int N, const double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
-                       const uint8_t* kind, int method, double phi, double delta, int apply_loss, double* r,
-                       double* J, int threads) {
+double pgo_oracle_eval_w(int N, const double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
+                         const double* info /* E x 6 or NULL */, const uint8_t* kind, int method, double phi,
+                         double delta, int apply_loss, double* r, double* J, int threads) {
   (void)N;
   double cost = 0.0;
   int bad = 0;
@@ -287,8 +383,9 @@ double pgo_oracle_eval(int N, const double* poses, int E, const int32_t* ia, con
     int dcs = (method == 1 && kind[e] != 0);
     const double* P1 = poses + 3 * (size_t)ia[e];
     const double* P2 = poses + 3 * (size_t)ib[e];
-    if (J) edge_functor_jet(P1, P2, meas + 3 * (size_t)e, dcs, phi, ee, JJ);
-    else edge_functor_double(P1, P2, meas + 3 * (size_t)e, dcs, phi, ee);
+    const double* w = info ? info + 6 * (size_t)e : NULL;
+    if (J) edge_functor_jet(P1, P2, meas + 3 * (size_t)e, w, dcs, phi, ee, JJ);
+    else edge_functor_double(P1, P2, meas + 3 * (size_t)e, w, dcs, phi, ee);
     double s = ee[0] * ee[0] + ee[1] * ee[1] + ee[2] * ee[2];
     double rho[3] = {s, 1.0, 0.0};
     if (delta > 0.0) huber(s, delta, rho);
@@ -305,6 +402,11 @@ double pgo_oracle_eval(int N, const double* poses, int E, const int32_t* ia, con
       }
   }
   return bad ? NAN : cost;
+}
+double pgo_oracle_eval(int N, const double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
+                       const uint8_t* kind, int method, double phi, double delta, int apply_loss, double* r,
+                       double* J, int threads) {
+  return pgo_oracle_eval_w(N, poses, E, ia, ib, meas, NULL, kind, method, phi, delta, apply_loss, r, J, threads);
 }
 
 /* METHOD 2, switchable constraints (main.cpp:115-125,138-145; src/ceres_error.cpp:237-317).  Residual blocks:
@@ -330,8 +432,8 @@ double pgo_oracle_eval_sc(int N, const double* poses, int E, const int32_t* ia, 
     const double* P1 = poses + 3 * (size_t)ia[e];
     const double* P2 = poses + 3 * (size_t)ib[e];
     const int want_j = (J != NULL) || (Js != NULL);
-    if (want_j) edge_functor_jet(P1, P2, meas + 3 * (size_t)e, 0, 0.5, ep, Jp);
-    else edge_functor_double(P1, P2, meas + 3 * (size_t)e, 0, 0.5, ep);
+    if (want_j) edge_functor_jet(P1, P2, meas + 3 * (size_t)e, NULL, 0, 0.5, ep, Jp);
+    else edge_functor_double(P1, P2, meas + 3 * (size_t)e, NULL, 0, 0.5, ep);
     const int sc_edge = kind[e] != 0;
     const double sv = sc_edge ? sw[e] : 1.0;
     double ee[3] = {sv * ep[0], sv * ep[1], sv * ep[2]};  /* product rule of Jet<7>: d e / d P = s d e_p / d P, d e / d s = e_p */
@@ -654,9 +756,9 @@ static int pcg(const normal_eq* Q, const double* b, double* y, double rtol, int 
   return it;
 }
 
-int pgo_oracle_lm_pcg(int N, double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
-                      const uint8_t* kind, const oracle_options* o, oracle_iter* recs, int cap, int* n_recs,
-                      oracle_summary* sum) {
+int pgo_oracle_lm_pcg_w(int N, double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
+                        const double* info /* E x 6 or NULL */, const uint8_t* kind, const oracle_options* o,
+                        oracle_iter* recs, int cap, int* n_recs, oracle_summary* sum) {
   int threads = o->threads > 0 ? o->threads : 1;
   size_t n = (size_t)3 * N;
   normal_eq Q;
@@ -681,7 +783,7 @@ int pgo_oracle_lm_pcg(int N, double* poses, int E, const int32_t* ia, const int3
   int fixed = o->fixed_pose;
 
   double t0 = now_s();
-  double cost = pgo_oracle_eval(N, poses, E, ia, ib, meas, kind, o->method, o->phi, o->huber_delta, 1, r, J, threads);
+  double cost = pgo_oracle_eval_w(N, poses, E, ia, ib, meas, info, kind, o->method, o->phi, o->huber_delta, 1, r, J, threads);
   t_eval += now_s() - t0;
   double initial_cost = cost;
   if (!isfinite(cost)) {
@@ -800,7 +902,7 @@ int pgo_oracle_lm_pcg(int N, double* poses, int E, const int32_t* ia, const int3
     }
     t0 = now_s();
     double cand_cost =
-        pgo_oracle_eval(N, cand, E, ia, ib, meas, kind, o->method, o->phi, o->huber_delta, 1, NULL, NULL, threads);
+        pgo_oracle_eval_w(N, cand, E, ia, ib, meas, info, kind, o->method, o->phi, o->huber_delta, 1, NULL, NULL, threads);
     t_cand += now_s() - t0;
     if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
     R.step_norm = sqrt(step2);
@@ -832,7 +934,7 @@ int pgo_oracle_lm_pcg(int N, double* poses, int E, const int32_t* ia, const int3
           for (int a = 0; a < 3; ++a) x_norm += poses[3 * (size_t)i + a] * poses[3 * (size_t)i + a];
       x_norm = sqrt(x_norm);
       t0 = now_s();
-      cost = pgo_oracle_eval(N, poses, E, ia, ib, meas, kind, o->method, o->phi, o->huber_delta, 1, r, J, threads);
+      cost = pgo_oracle_eval_w(N, poses, E, ia, ib, meas, info, kind, o->method, o->phi, o->huber_delta, 1, r, J, threads);
       t_eval += now_s() - t0;
       if (!isfinite(cost)) {
         term = 6;
@@ -900,8 +1002,9 @@ done:
 
 /* y = H x (+ D2 x) for an explicit scale vector / radius: SpMV parity helper.
  * Builds the scaled normal equations at `poses` and multiplies.               */
-int pgo_oracle_normal_eq(int N, const double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
-                         const uint8_t* kind, int method, double phi, double delta, int fixed_pose,
+int pgo_oracle_normal_eq_w(int N, const double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
+                           const double* info /* E x 6 or NULL */, const uint8_t* kind, int method, double phi,
+                           double delta, int fixed_pose,
                          const double* s_or_null, double* g_out /*3N*/, double* hdiag_out /*N x 9*/,
                          const double* x_or_null, double* y_or_null, int threads) {
   size_t n = (size_t)3 * N;
@@ -916,7 +1019,7 @@ int pgo_oracle_normal_eq(int N, const double* poses, int E, const int32_t* ia, c
   double* J = (double*)malloc((size_t)E * 18 * sizeof(double));
   double* s = (double*)malloc(n * sizeof(double));
   double* gs = (double*)malloc(n * sizeof(double));
-  pgo_oracle_eval(N, poses, E, ia, ib, meas, kind, method, phi, delta, 1, r, J, threads);
+  pgo_oracle_eval_w(N, poses, E, ia, ib, meas, info, kind, method, phi, delta, 1, r, J, threads);
   for (size_t i = 0; i < n; ++i) s[i] = s_or_null ? s_or_null[i] : 1.0;
   if (fixed_pose >= 0) s[3 * fixed_pose] = s[3 * fixed_pose + 1] = s[3 * fixed_pose + 2] = 0.0;
   assemble(&Q, r, J, s, gs, threads);
@@ -929,4 +1032,17 @@ int pgo_oracle_normal_eq(int N, const double* poses, int E, const int32_t* ia, c
   free(gs);
   free_normal_eq(&Q);
   return 0;
+}
+
+int pgo_oracle_lm_pcg(int N, double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
+                      const uint8_t* kind, const oracle_options* o, oracle_iter* recs, int cap, int* n_recs,
+                      oracle_summary* sum) {
+  return pgo_oracle_lm_pcg_w(N, poses, E, ia, ib, meas, NULL, kind, o, recs, cap, n_recs, sum);
+}
+int pgo_oracle_normal_eq(int N, const double* poses, int E, const int32_t* ia, const int32_t* ib, const double* meas,
+                         const uint8_t* kind, int method, double phi, double delta, int fixed_pose,
+                         const double* s_or_null, double* g_out, double* hdiag_out, const double* x_or_null,
+                         double* y_or_null, int threads) {
+  return pgo_oracle_normal_eq_w(N, poses, E, ia, ib, meas, NULL, kind, method, phi, delta, fixed_pose, s_or_null, g_out,
+                                hdiag_out, x_or_null, y_or_null, threads);
 }

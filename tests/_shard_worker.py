@@ -27,6 +27,8 @@ def main():
     summ = s.solve()
     out = dict(cost0=c0, summary=summ.as_dict(), records=s.iter_records())
     np.save(os.path.join(cfg["out"], "poses_%d.npy" % rank), s.poses())
+    if cfg.get("chi2"):
+        np.save(os.path.join(cfg["out"], "chi2_%d.npy" % rank), s.edge_chi2())
     json.dump(out, open(os.path.join(cfg["out"], "out_%d.json" % rank), "w"))
     s.close()
     if comm:

@@ -18,7 +18,41 @@ DATA = os.path.join(ROOT, "tests", "golden", "data")
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+def info_cases():
+    """optional information-weighted mode (oracle/pgo_oracle.c edge_functor_jet with info): LM traces,
+    per-edge chi2 (compute_edge_mahalanobis) and whitened residual/Jacobian vectors"""
+    for name, n_out, method in [("INTEL", 50, 1), ("M3500", 0, 1), ("MIT", 0, 0)]:
+        gg = O.read_g2o(os.path.join(DATA, name + ".g2o"))
+        if n_out:
+            gg = O.add_random_C(gg, n_out, 1)
+        res = O.lm_direct(gg, O.Options(method=method, info_weighting=1, phi=1.0))
+        tag = "%s_out%d_m%d_info" % (name, n_out, method)
+        np.save(os.path.join(OUT, "lm_%s_poses.npy" % tag), res.poses)
+        json.dump(dict(dataset=name, outliers=n_out, seed=1, method=method, info_weighting=1, phi=1.0,
+                       termination=res.termination, iterations=res.iterations, initial_cost=res.initial_cost,
+                       final_cost=res.final_cost, records=res.records), open(os.path.join(OUT, "lm_%s.json" % tag), "w"), indent=1)
+        print(tag, O.TERM[res.termination], res.iterations, res.final_cost)
+    chi = {}
+    for name in ["INTEL", "M3500", "MIT", "CSAIL", "FR079", "FRH"]:
+        gg = O.read_g2o(os.path.join(DATA, name + ".g2o"))
+        c = O.edge_chi2(gg)
+        chi[name] = dict(sum=float(c.sum()), max=float(c.max()), n_zero=int((c == 0).sum()), first=c[:5].tolist(), last=c[-5:].tolist())
+    g = O.read_g2o(os.path.join(DATA, "INTEL.g2o"))
+    edges = []
+    for k in list(range(0, 5)) + list(range(1227, 1232)):
+        rec = dict(edge=int(k), info=g.info[k].tolist())
+        for dcs in (0, 1):
+            e, J = O.edge(g.poses[g.ia[k]], g.poses[g.ib[k]], g.meas[k], bool(dcs), 1.0, True, g.info[k])
+            rec["e%d" % dcs] = e.tolist()
+            rec["J%d" % dcs] = J.reshape(-1).tolist()
+        edges.append(rec)
+    json.dump(dict(chi2=chi, intel_edges_phi1=edges), open(os.path.join(OUT, "info_mode.json"), "w"), indent=1)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "info":
+        return info_cases()
+    info_cases()
     # per-edge residual / Jacobian vectors for 20 INTEL edges, both functors
     g = O.read_g2o(os.path.join(DATA, "INTEL.g2o"))
     idx = list(range(0, 10)) + list(range(1227, 1237))

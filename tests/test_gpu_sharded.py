@@ -98,3 +98,22 @@ def test_sharded_switchable_constraints(tmp_path, world, halo):
             assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-9)
             assert a["gradient_max_norm"] == pytest.approx(b["gradient_max_norm"], rel=1e-7)
     assert np.abs(poses[0] - ref_poses[0]).max() < 1e-7
+
+
+@pytest.mark.parametrize("world,halo", [(2, 1), (3, 0)])
+def test_sharded_info_weighting_and_chi2(tmp_path, world, halo):
+    """information-weighted mode (128-byte records) and pgo_edge_chi2 across ranks: cut edges are whitened on both
+    owners; the chi2 vector is assembled by one all-reduce and is identical on every rank"""
+    cfg = dict(graph="M3500", chi2=1,
+               options=dict(method=1, info_weighting=1, phi=1.0, max_iters=4, pcg_rtol=1e-11, pcg_max_iters=60000))
+    ref, ref_poses = run(1, cfg, tmp_path)
+    ref_chi2 = np.load(os.path.join(str(tmp_path), "w1", "chi2_0.npy"))
+    cfg = dict(cfg, options=dict(cfg["options"], halo_exchange=halo))
+    res, poses = run(world, cfg, tmp_path, tag="info%d" % halo)
+    for r in range(world):
+        np.testing.assert_array_equal(poses[r], poses[0])
+        for a, b in zip(res[r]["records"], ref[0]["records"]):
+            assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-9)
+        chi2 = np.load(os.path.join(str(tmp_path), "w%dinfo%d" % (world, halo), "chi2_%d.npy" % r))
+        np.testing.assert_allclose(chi2, ref_chi2, rtol=1e-6, atol=1e-9)  # evaluated at the solved poses (1e-7 apart)
+    assert np.abs(poses[0] - ref_poses[0]).max() < 1e-7

@@ -219,3 +219,91 @@ def test_switchable_lm_regression(oracle):
     for a, b in zip(res.records, fx["records"][:11]):
         assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-9)
     assert res.initial_cost == pytest.approx(3.964897979485657e+01, rel=1e-12)  # == METHOD 0 cost at s = 1
+
+
+# ------------------------------------------------- optional information-weighted mode
+def _closed_form_plain(P1, P2, m):
+    """independent closed form of the plain SE(2) error, numpy"""
+    c1, s1 = np.cos(P1[2]), np.sin(P1[2])
+    D = P2[:2] - P1[:2]
+    a, b = c1 * D[0] + s1 * D[1], -s1 * D[0] + c1 * D[1]
+    u = np.array([a - m[0], b - m[1]])
+    cd, sd = np.cos(m[2]), np.sin(m[2])
+    return np.array([cd * u[0] + sd * u[1], -sd * u[0] + cd * u[1], np.arcsin(np.sin(P2[2] - P1[2] - m[2]))])
+
+
+def _omega(w):
+    return np.array([[w[0], w[1], w[2]], [w[1], w[3], w[4]], [w[2], w[4], w[5]]])
+
+
+def test_edge_chi2_is_the_reference_mahalanobis_formula(oracle):
+    """compute_edge_mahalanobis (src/layer_manager.cpp:230-282): m = r' Omega r, r plain, clamped at 0; checked against
+    an independent numpy closed form on every edge of an EDGE_SE2 file and of an EDGE2 file (indefinite Omega there)"""
+    fx = json.load(open(os.path.join(GOLDEN, "info_mode.json")))["chi2"]
+    for name in ("INTEL", "CSAIL"):
+        g = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
+        got = oracle.edge_chi2(g)
+        exp = np.empty(g.n_edges)
+        for k in range(g.n_edges):
+            r = _closed_form_plain(g.poses[g.ia[k]], g.poses[g.ib[k]], g.meas[k])
+            exp[k] = max(0.0, r @ _omega(g.info[k]) @ r)
+        np.testing.assert_allclose(got, exp, rtol=1e-9, atol=1e-9 * exp.max())
+        assert got.sum() == pytest.approx(fx[name]["sum"], rel=1e-12)
+        assert int((got == 0).sum()) == fx[name]["n_zero"]
+    assert fx["CSAIL"]["n_zero"] > 10  # clamped negatives: the EDGE2 entries read positionally are not a PSD matrix
+
+
+def test_info_weighting_whitens_and_uses_chi2_dcs(oracle):
+    g = oracle.read_g2o(os.path.join(DATA, "INTEL.g2o"))
+    rng = np.random.default_rng(3)
+    for k in (0, 500, 1230, 1400):
+        P1, P2, m, w = g.poses[g.ia[k]], g.poses[g.ib[k]] + 0.05 * rng.standard_normal(3), g.meas[k], g.info[k]
+        r = _closed_form_plain(P1, P2, m)
+        L = np.linalg.cholesky(_omega(w))
+        ew = L.T @ r
+        e0 = oracle.edge(P1, P2, m, False, 1.0, False, w)
+        np.testing.assert_allclose(e0, ew, rtol=1e-10, atol=1e-12)
+        assert e0 @ e0 == pytest.approx(r @ _omega(w) @ r, rel=1e-10)
+        chi2 = ew @ ew
+        sc = min(1.0, 2.0 * 1.0 / (1.0 + chi2))
+        e1, J1 = oracle.edge(P1, P2, m, True, 1.0, True, w)
+        np.testing.assert_allclose(e1, sc * ew, rtol=1e-10, atol=1e-12)
+        # Jacobian against central differences of the oracle's own double-precision functor
+        h = 1e-6
+        Jn = np.zeros((3, 6))
+        for c in range(6):
+            a, b, aa, bb = P1.copy(), P2.copy(), P1.copy(), P2.copy()
+            (a if c < 3 else b)[c % 3] += h
+            (aa if c < 3 else bb)[c % 3] -= h
+            Jn[:, c] = (oracle.edge(a, b, m, True, 1.0, False, w) - oracle.edge(aa, bb, m, True, 1.0, False, w)) / (2 * h)
+        assert np.abs(Jn - J1).max() < 1e-6 * max(1.0, np.abs(J1).max())
+    # identity information == the unweighted METHOD 0 objective
+    g2 = g.copy()
+    g2.info = np.tile(np.array([1.0, 0, 0, 1.0, 0, 1.0]), (g.n_edges, 1))
+    c_w, r_w, J_w = oracle.evaluate(g2, method=0, info_weighting=True)
+    c_p, r_p, J_p = oracle.evaluate(g, method=0)
+    assert c_w == c_p
+    np.testing.assert_array_equal(r_w, r_p)
+    np.testing.assert_array_equal(J_w, J_p)
+    # an indefinite information matrix poisons the evaluation instead of producing numbers
+    gb = oracle.read_g2o(os.path.join(DATA, "CSAIL.g2o"))
+    assert np.isnan(oracle.evaluate(gb, method=0, want_r=False, want_J=False, info_weighting=True)[0])
+
+
+def test_info_mode_fixture_regression(oracle):
+    fx = json.load(open(os.path.join(GOLDEN, "info_mode.json")))["intel_edges_phi1"]
+    g = oracle.read_g2o(os.path.join(DATA, "INTEL.g2o"))
+    for rec in fx:
+        k = rec["edge"]
+        for dcs in (0, 1):
+            e, J = oracle.edge(g.poses[g.ia[k]], g.poses[g.ib[k]], g.meas[k], bool(dcs), 1.0, True, g.info[k])
+            np.testing.assert_allclose(e, rec["e%d" % dcs], rtol=1e-13, atol=1e-15)
+            np.testing.assert_allclose(J.reshape(-1), rec["J%d" % dcs], rtol=1e-12, atol=1e-13)
+    f = json.load(open(os.path.join(GOLDEN, "lm_MIT_out0_m0_info.json")))
+    gm = oracle.read_g2o(os.path.join(DATA, "MIT.g2o"))
+    res = oracle.lm_direct(gm, oracle.Options(method=0, info_weighting=1, phi=1.0))
+    assert res.termination == f["termination"] and res.iterations == f["iterations"]
+    assert res.final_cost == pytest.approx(f["final_cost"], rel=1e-9)
+    # the C port (PCG) follows the same trajectory in this mode too
+    port = oracle.lm_pcg(gm, oracle.Options(method=0, info_weighting=1, phi=1.0, max_iters=10, pcg_rtol=1e-12, pcg_block_poses=32))
+    assert port.records[10]["cost"] == pytest.approx(f["records"][10]["cost"], rel=1e-6)

@@ -36,7 +36,7 @@ EXPORTS = [
     "pgo_graph_edge_kind", "pgo_inject_outliers", "pgo_write_nodes", "pgo_write_edges", "pgo_write_g2o",
     "pgo_synth_manhattan", "pgo_options_default",
     "pgo_comm_unique_id", "pgo_comm_create_rccl", "pgo_comm_create_shm", "pgo_comm_destroy",
-    "pgo_create", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_solve", "pgo_lm_begin", "pgo_lm_step",
+    "pgo_create", "pgo_create_weighted", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_edge_chi2", "pgo_solve", "pgo_lm_begin", "pgo_lm_step",
     "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
     "pgo_write_switches",
     "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_debug_spmv", "pgo_debug_normal_eq",
@@ -59,7 +59,8 @@ class Options(C.Structure):
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
                 ("max_lm_diagonal", C.c_double), ("pcg_rtol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("pcg_check_every", C.c_int32), ("verbose", C.c_int32),
-                ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("sc_prior_lambda", C.c_double), ("pose_ordering", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("sc_prior_lambda", C.c_double), ("pose_ordering", C.c_int32), ("info_weighting", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -149,7 +150,9 @@ def lib():
     L.pgo_comm_destroy.argtypes = [vp]
     L.pgo_comm_destroy.restype = None
     L.pgo_create.argtypes = [C.POINTER(vp), C.c_int32, dp, C.c_int32, ip, ip, dp, bp, C.POINTER(Options), vp, C.c_int]
+    L.pgo_create_weighted.argtypes = [C.POINTER(vp), C.c_int32, dp, C.c_int32, ip, ip, dp, dp, bp, C.POINTER(Options), vp, C.c_int]
     L.pgo_create_from_graph.argtypes = [C.POINTER(vp), vp, C.POINTER(Options), vp, C.c_int]
+    L.pgo_edge_chi2.argtypes = [vp, dp, dp]
     L.pgo_destroy.argtypes = [vp]
     L.pgo_destroy.restype = None
     L.pgo_eval.argtypes = [vp, dp, C.c_int, dp, dp, dp]
@@ -410,6 +413,13 @@ class Solver:
         cost = C.c_double()
         _check(lib().pgo_eval(self._h, _dp(p), int(apply_loss), C.byref(cost), _dp(r), _dp(J)))
         return cost.value, r, J
+
+    def edge_chi2(self, poses=None):
+        """r' Omega r of the plain residual per edge (compute_edge_mahalanobis, src/layer_manager.cpp:230-282)"""
+        p = np.ascontiguousarray(poses, np.float64) if poses is not None else None
+        out = np.zeros(self.n_edges)
+        _check(lib().pgo_edge_chi2(self._h, _dp(p), _dp(out)))
+        return out
 
     def solve(self) -> Summary:
         s = Summary()

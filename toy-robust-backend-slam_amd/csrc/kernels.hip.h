@@ -25,6 +25,16 @@ constexpr int WG = 256;          // workgroup size of every kernel here (4 waves
 // so storing it would only repeat 8 of its 9 entries.
 constexpr int REC = 14;
 constexpr int REC_LDS = 15;      // odd stride => conflict-free ds_write_b64 when staging records
+// Information-weighted mode (pgo_options.info_weighting): whitening by L' (Omega = L L') mixes the rows and the chi2 form
+// of DCS makes grad psi depend on theta2, so the last column of d e/d P2 is a general 3-vector b3:
+//     record = A (9) | b3 (3) | r (3) | cost = 16 doubles = 128 B,   d e/d P2 = [ -A[:,0] | -A[:,1] | b3 ]
+// (the error still depends on the positions only through P2 - P1, so the first two columns stay implied).
+constexpr int REC_INFO = 16;
+template <bool INFO> struct RecLayout {
+  static constexpr int N = INFO ? REC_INFO : REC;   // doubles per record
+  static constexpr int LDS = N + 1;                 // odd staging stride
+  static constexpr int R0 = INFO ? 12 : 10;         // first residual entry
+};
 constexpr int PS = 3;            // doubles per pose in the GATHERED vector p.  Padding to 4 (32 B, never straddling a
                                  // 64-byte sector) was measured: no fewer fetched bytes (FETCH_SIZE 566 vs 557 MiB), so 3.
 
@@ -111,14 +121,34 @@ struct EdgeArgs {
   const double* sw;       // [n_edges] switch per local edge
   double* sw_js;          // [n_edges x 3] out (with the Jacobian): d e / d s after the Huber corrector
   double sc_lambda;
+  // information matrices, 6 planes [6][n_edges]: I11 I12 I13 I22 I23 I33 (include/graph.h:41-47); nullptr when the handle
+  // was created without them.  Read by k_edge_eval<*, true> and k_edge_chi2 only.
+  const double* info;
 };
 
+// Cholesky factor of a 3x3 information matrix, Omega = L L' (positive definiteness is checked on the host at create)
+struct Chol3 {
+  double l00, l10, l11, l20, l21, l22;
+};
+__device__ __forceinline__ Chol3 chol3(double w00, double w01, double w02, double w11, double w12, double w22) {
+  Chol3 c;
+  c.l00 = sqrt(w00);
+  const double i0 = 1.0 / c.l00;
+  c.l10 = w01 * i0;
+  c.l20 = w02 * i0;
+  c.l11 = sqrt(w11 - c.l10 * c.l10);
+  c.l21 = (w12 - c.l20 * c.l10) / c.l11;
+  c.l22 = sqrt(w22 - c.l20 * c.l20 - c.l21 * c.l21);
+  return c;
+}
+
 // One lane per edge.  Algorithmic bytes per edge: 8 (ia,ib) + 24 (meas) + 1 (flags) +
-// 48 (two poses) read, 112 written with the Jacobian, 0 without.
-template <bool WITH_JAC>
+// 48 (two poses) read, 112 written with the Jacobian, 0 without (INFO: + 48 read, 128 written).
+template <bool WITH_JAC, bool INFO>
 __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict__ jr,
                                                   double* __restrict__ cost_part, int* __restrict__ bad) {
-  __shared__ double stage[WITH_JAC ? WG * REC_LDS : 1];
+  constexpr int RN = RecLayout<INFO>::N, RL = RecLayout<INFO>::LDS;
+  __shared__ double stage[WITH_JAC ? WG * RL : 1];
   __shared__ double red[8];
   const int tid = threadIdx.x;
   // XCD-aware: consecutive 256-edge blocks (sorted by min endpoint => shared pose sectors) share an XCD
@@ -155,9 +185,43 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
       J[6] = sm;   J[7] = -cm;  J[8] = -sd * pb - cd * pa;  J[9] = -sm;  J[10] = cm;  J[11] = 0.0;
       J[12] = 0.0; J[13] = 0.0; J[14] = -g;                 J[15] = 0.0; J[16] = 0.0; J[17] = g;
     }
+    if (INFO) {  // whiten: e <- L' e, J <- L' J  (|e|^2 becomes e' Omega e)
+      const int64_t ne = A.n_edges;
+      const Chol3 c = chol3(A.info[e], A.info[ne + e], A.info[2 * ne + e], A.info[3 * ne + e], A.info[4 * ne + e],
+                            A.info[5 * ne + e]);
+      const double w0 = c.l00 * ex + c.l10 * ey + c.l20 * et, w1 = c.l11 * ey + c.l21 * et, w2 = c.l22 * et;
+      ex = w0; ey = w1; et = w2;
+      if (WITH_JAC) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const double j0 = J[k], j1 = J[6 + k], j2 = J[12 + k];
+          J[k] = c.l00 * j0 + c.l10 * j1 + c.l20 * j2;
+          J[6 + k] = c.l11 * j1 + c.l21 * j2;
+          J[12 + k] = c.l22 * j2;
+        }
+      }
+    }
     const bool switchable = (fl & 1u) && A.sw != nullptr;
     double sval = 1.0, epx = 0.0, epy = 0.0, ept = 0.0;
-    if (switchable) {  // e = s e_plain ; d e / d P = s d e_plain / d P ; d e / d s = e_plain
+    if (INFO && (fl & 1u)) {  // chi2 form of DCS: s = min(1, 2 phi / (phi + chi2)), chi2 = |e_w|^2, e = s e_w
+      const double chi2 = ex * ex + ey * ey + et * et;
+      const double sdc = 2.0 * A.phi / (A.phi + chi2);
+      if (sdc < 1.0) {
+        if (WITH_JAC) {
+          const double k = -2.0 * sdc / (A.phi + chi2);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const double ds = k * (ex * J[c] + ey * J[6 + c] + et * J[12 + c]);
+            J[c] = sdc * J[c] + ex * ds;
+            J[6 + c] = sdc * J[6 + c] + ey * ds;
+            J[12 + c] = sdc * J[12 + c] + et * ds;
+          }
+        }
+        ex *= sdc;
+        ey *= sdc;
+        et *= sdc;
+      }
+    } else if (switchable) {  // e = s e_plain ; d e / d P = s d e_plain / d P ; d e / d s = e_plain
       sval = A.sw[e];
       epx = ex; epy = ey; ept = et;
       ex *= sval; ey *= sval; et *= sval;
@@ -204,7 +268,7 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
     if (fl & 2u) cost = ecost;
     bool finite = isfinite(s);
     if (WITH_JAC) {
-      double* st = stage + tid * REC_LDS;
+      double* st = stage + tid * RL;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const double v0 = sc * J[6 * i + 0], v1 = sc * J[6 * i + 1], v2 = sc * J[6 * i + 2];
@@ -213,13 +277,22 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
         st[3 * i + 1] = v1;
         st[3 * i + 2] = v2;
       }
-      const double g2 = sc * J[17];
-      finite = finite && isfinite(g2);
-      st[9] = g2;
-      st[10] = sc * ex;
-      st[11] = sc * ey;
-      st[12] = sc * et;
-      st[13] = ecost;
+      if (INFO) {
+        const double b0 = sc * J[5], b1 = sc * J[11], b2 = sc * J[17];
+        finite = finite && isfinite(b0) && isfinite(b1) && isfinite(b2);
+        st[9] = b0;
+        st[10] = b1;
+        st[11] = b2;
+      } else {
+        const double g2 = sc * J[17];
+        finite = finite && isfinite(g2);
+        st[9] = g2;
+      }
+      constexpr int R0 = RecLayout<INFO>::R0;
+      st[R0] = sc * ex;
+      st[R0 + 1] = sc * ey;
+      st[R0 + 2] = sc * et;
+      st[R0 + 3] = ecost;
       if (switchable) {
         double* js = A.sw_js + 3 * e;
         js[0] = sc * epx;
@@ -235,18 +308,48 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
     __syncthreads();
     int64_t nvalid = live ? A.n_edges - e0 : 0;
     if (nvalid > WG) nvalid = WG;
-    const int ndbl = (int)nvalid * REC;
-    double* out = jr + e0 * REC;  // 16-byte aligned: e0 * 112
+    const int ndbl = (int)nvalid * RN;
+    double* out = jr + e0 * RN;  // 16-byte aligned: e0 * 112 (128)
     for (int j = tid * 2; j < ndbl; j += 2 * WG) {
-      const int le = j / REC, c = j - le * REC;  // REC is even => (j, j+1) stay in one record
+      const int le = j / RN, c = j - le * RN;  // RN is even => (j, j+1) stay in one record
       double2 v;
-      v.x = stage[le * REC_LDS + c];
-      v.y = stage[le * REC_LDS + c + 1];
+      v.x = stage[le * RL + c];
+      v.y = stage[le * RL + c + 1];
       *reinterpret_cast<double2*>(out + j) = v;
     }
   }
   const double tot = block_sum_bcast(cost, red);
   if (tid == 0) cost_part[blockIdx.x] = tot;
+}
+
+// compute_edge_mahalanobis (src/layer_manager.cpp:230-282) for every local edge that this rank counts (flags bit1):
+// m = r' Omega r of the PLAIN residual r = (ex, ey, asin(clamp(sin delta))), clamped at 0, written to the caller's edge
+// index.  Any symmetric Omega (no factorisation).  57 B read + 48 B information + 8 B written per edge.
+__global__ __launch_bounds__(WG) void k_edge_chi2(EdgeArgs A, const int32_t* __restrict__ orig_edge, double* __restrict__ out) {
+  const int64_t ne = A.n_edges;
+  for (int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x; e < ne; e += (int64_t)gridDim.x * WG) {
+    if (!(A.flags[e] & 2u)) continue;
+    const int a = A.ia[e], b = A.ib[e];
+    const double dx = A.mx[e], dy = A.my[e], dth = A.mt[e];
+    const double x1 = A.poses[3 * (int64_t)a], y1 = A.poses[3 * (int64_t)a + 1], t1 = A.poses[3 * (int64_t)a + 2];
+    const double x2 = A.poses[3 * (int64_t)b], y2 = A.poses[3 * (int64_t)b + 1], t2 = A.poses[3 * (int64_t)b + 2];
+    double s1, c1, s2, c2, sd, cd;
+    sincos(t1, &s1, &c1);
+    sincos(t2, &s2, &c2);
+    sincos(dth, &sd, &cd);
+    const double Dx = x2 - x1, Dy = y2 - y1;
+    const double pa = c1 * Dx + s1 * Dy, pb = -s1 * Dx + c1 * Dy;
+    const double ux = pa - dx, uy = pb - dy;
+    const double ex = cd * ux + sd * uy, ey = -sd * ux + cd * uy;
+    const double c21 = c1 * c2 + s1 * s2, s21 = c1 * s2 - s1 * c2;
+    const double sind = cd * s21 - sd * c21;
+    const double et = asin(fmin(1.0, fmax(-1.0, sind)));
+    const double w00 = A.info[e], w01 = A.info[ne + e], w02 = A.info[2 * ne + e], w11 = A.info[3 * ne + e],
+                 w12 = A.info[4 * ne + e], w22 = A.info[5 * ne + e];
+    const double m = ex * (w00 * ex + w01 * ey + w02 * et) + ey * (w01 * ex + w11 * ey + w12 * et) +
+                     et * (w02 * ex + w12 * ey + w22 * et);
+    out[orig_edge[e]] = m < 0.0 ? 0.0 : m;
+  }
 }
 
 // ------------------------------------------------------------------- K2
@@ -291,8 +394,10 @@ struct AsmArgs {
 // (9 doubles, staged in LDS).  Phase B: one thread per (row, component) sums its
 // row's staged contributions in incidence order -- a fixed order, so the result is
 // bitwise reproducible and independent of the sharding.
-template <bool SC>
+template <bool SC, bool INFO>
 __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
+  static_assert(!(SC && INFO), "switchable constraints have no information-weighted form here");
+  constexpr int RN = RecLayout<INFO>::N, R0 = RecLayout<INFO>::R0;
   constexpr int NS = SC ? 15 : 9;  // staged values per incidence
   __shared__ double scr[NS][WG];
   const int tid = threadIdx.x;
@@ -308,10 +413,10 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
       if (q < q1) {
         const int ed = A.inc_edge[q];
         const int64_t col = A.inc_col[q];
-        const double2* rp = reinterpret_cast<const double2*>(A.jr + (int64_t)(ed >> 1) * REC);
-        double R[REC];
+        const double2* rp = reinterpret_cast<const double2*>(A.jr + (int64_t)(ed >> 1) * RN);
+        double R[RN];
 #pragma unroll
-        for (int k = 0; k < REC / 2; ++k) {
+        for (int k = 0; k < RN / 2; ++k) {
           const double2 v = rp[k];
           R[2 * k] = v.x;
           R[2 * k + 1] = v.y;
@@ -332,7 +437,7 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const double a0 = R[3 * k], a1 = R[3 * k + 1], a2 = R[3 * k + 2];
-          const double b2 = (k == 2) ? R[9] : 0.0;
+          const double b2 = INFO ? R[9 + k] : ((k == 2) ? R[9] : 0.0);
           const double x0 = self_is_a ? a0 : -a0, x1 = self_is_a ? a1 : -a1, x2 = self_is_a ? a2 : b2;
           const double y0 = self_is_a ? -a0 : a0, y1 = self_is_a ? -a1 : a1, y2 = self_is_a ? b2 : a2;
           S[3 * k] = x0 * ss[0]; S[3 * k + 1] = x1 * ss[1]; S[3 * k + 2] = x2 * ss[2];
@@ -340,7 +445,7 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
         }
         // METHOD 2: elimination coefficients of this edge's switch (c == 0 for ordinary edges)
         double cc = 0.0, gam = 0.0, vs[3] = {0.0, 0.0, 0.0}, vo[3] = {0.0, 0.0, 0.0};
-        if (SC) {
+        if constexpr (SC) {
           const int64_t le = ed >> 1;
           cc = A.sw_c[le];
           if (cc != 0.0) {
@@ -358,15 +463,15 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
             double v = S[a] * O[b] + S[3 + a] * O[3 + b] + S[6 + a] * O[6 + b];
-            if (SC) v -= cc * vs[a] * vo[b];  // J'(I - c j j')J
+            if constexpr (SC) v -= cc * vs[a] * vo[b];  // J'(I - c j j')J
             A.hoff[hoff_index(3 * a + b, q)] = v;
           }
         double d0 = S[0] * S[0] + S[3] * S[3] + S[6] * S[6], d1 = S[0] * S[1] + S[3] * S[4] + S[6] * S[7];
         double d2 = S[0] * S[2] + S[3] * S[5] + S[6] * S[8], d3 = S[1] * S[1] + S[4] * S[4] + S[7] * S[7];
         double d4 = S[1] * S[2] + S[4] * S[5] + S[7] * S[8], d5 = S[2] * S[2] + S[5] * S[5] + S[8] * S[8];
-        double g0 = S[0] * R[10] + S[3] * R[11] + S[6] * R[12], g1 = S[1] * R[10] + S[4] * R[11] + S[7] * R[12];
-        double g2 = S[2] * R[10] + S[5] * R[11] + S[8] * R[12];
-        if (SC) {
+        double g0 = S[0] * R[R0] + S[3] * R[R0 + 1] + S[6] * R[R0 + 2], g1 = S[1] * R[R0] + S[4] * R[R0 + 1] + S[7] * R[R0 + 2];
+        double g2 = S[2] * R[R0] + S[5] * R[R0 + 1] + S[8] * R[R0 + 2];
+        if constexpr (SC) {
           scr[9][tid] = d0;  scr[10][tid] = d3; scr[11][tid] = d5;   // unreduced diagonal and gradient
           scr[12][tid] = g0; scr[13][tid] = g1; scr[14][tid] = g2;
           d0 -= cc * vs[0] * vs[0]; d1 -= cc * vs[0] * vs[1]; d2 -= cc * vs[0] * vs[2];

@@ -69,6 +69,13 @@ struct pgo_handle {
   double *e_mx = nullptr, *e_my = nullptr, *e_mt = nullptr;
   uint8_t* e_flags = nullptr;
   double* jr = nullptr;
+  // information matrices (6 planes over the local edges); info_mode = opt.info_weighting with them present
+  double* e_info = nullptr;
+  bool info_mode = false;
+  int rec_doubles = dev::REC;
+  int32_t* e_orig = nullptr;   // local edge -> caller's edge index (device copy, for pgo_edge_chi2)
+  double* chi2_buf = nullptr;  // [n_edges_total], allocated at the first pgo_edge_chi2
+  int64_t n_edges_total = 0;
   int32_t *inc_ptr = nullptr, *inc_edge = nullptr, *inc_col = nullptr, *tile_row = nullptr;
   int64_t inc_stride = 0;
   // normal equations
@@ -231,6 +238,7 @@ struct pgo_handle {
     A.sw = has_sw ? sw_vals : nullptr;
     A.sw_js = sw_js;
     A.sc_lambda = opt.sc_prior_lambda;
+    A.info = e_info;
     return A;
   }
   dev::SwitchArrays switch_arrays() const {
@@ -251,8 +259,13 @@ struct pgo_handle {
   }
   void launch_eval(const double* x, const double* sw_vals, int apply_loss, bool with_jac) {
     dev::EdgeArgs A = edge_args(x, sw_vals, apply_loss);
-    if (with_jac) hipLaunchKernelGGL(dev::k_edge_eval<true>, dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
-    else hipLaunchKernelGGL(dev::k_edge_eval<false>, dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
+    if (info_mode) {
+      if (with_jac) hipLaunchKernelGGL((dev::k_edge_eval<true, true>), dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
+      else hipLaunchKernelGGL((dev::k_edge_eval<false, true>), dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
+    } else {
+      if (with_jac) hipLaunchKernelGGL((dev::k_edge_eval<true, false>), dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
+      else hipLaunchKernelGGL((dev::k_edge_eval<false, false>), dim3(g_edge), dim3(dev::WG), 0, stream, A, jr, part[5], bad);
+    }
   }
   // evaluates at x; on return h_scal[slot] = cost, h_scal[slot+1] = #bad flags (needs fetch by caller)
   int eval_enqueue(const double* x, const double* sw_vals, int apply_loss, bool with_jac, int slot) {
@@ -289,8 +302,9 @@ struct pgo_handle {
   }
   int assemble_enqueue() {
     if (S.n_tiles() == 0) return PGO_OK;
-    if (has_sw) hipLaunchKernelGGL(dev::k_assemble<true>, dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
-    else hipLaunchKernelGGL(dev::k_assemble<false>, dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
+    if (has_sw) hipLaunchKernelGGL((dev::k_assemble<true, false>), dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
+    else if (info_mode) hipLaunchKernelGGL((dev::k_assemble<false, true>), dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
+    else hipLaunchKernelGGL((dev::k_assemble<false, false>), dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
     return check_launch("k_assemble");
   }
 
@@ -340,7 +354,7 @@ struct pgo_handle {
   }
 
   int create(int32_t N, const double* poses_h, int32_t E, const int32_t* ia, const int32_t* ib, const double* meas,
-             const uint8_t* kind);
+             const double* info6, const uint8_t* kind);
   int linearize(bool reuse_records, bool assemble = true);
   int refresh_switch_system();
   int lm_begin();
@@ -351,8 +365,28 @@ struct pgo_handle {
 
 // --------------------------------------------------------------------- create
 int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_t* ia, const int32_t* ib,
-                       const double* meas, const uint8_t* kind) {
+                       const double* meas, const double* info6, const uint8_t* kind) {
   const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+  n_edges_total = E;
+  info_mode = opt.info_weighting != 0;
+  if (info_mode) {
+    if (!info6) return fail(PGO_ERR_INVALID_ARG, "info_weighting = 1 needs the information matrices (pgo_create_weighted / pgo_create_from_graph)");
+    if (opt.method == 2) return fail(PGO_ERR_UNSUPPORTED, "info_weighting is implemented for METHOD 0 and 1 only");
+    for (int32_t e = 0; e < E; ++e) {  // every Omega must have a Cholesky factor
+      const double* w = info6 + 6 * (size_t)e;
+      const double l00 = w[0] > 0.0 ? std::sqrt(w[0]) : 0.0;
+      const double l10 = l00 > 0.0 ? w[1] / l00 : 0.0, l20 = l00 > 0.0 ? w[2] / l00 : 0.0;
+      const double d1 = w[3] - l10 * l10;
+      const double l11 = d1 > 0.0 ? std::sqrt(d1) : 0.0;
+      const double l21 = l11 > 0.0 ? (w[4] - l20 * l10) / l11 : 0.0;
+      const double d2v = w[5] - l20 * l20 - l21 * l21;
+      if (!(w[0] > 0.0) || !(d1 > 0.0) || !(d2v > 0.0) || !std::isfinite(d2v))
+        return fail(PGO_ERR_NUMERIC, "info_weighting: the information matrix of edge " + std::to_string(e) +
+                                         " is not positive definite (EDGE2 files are read positionally like EDGE_SE2, "
+                                         "reference g2o_util.h:53-66)");
+    }
+    rec_doubles = dev::REC_INFO;
+  }
   const char* fc = getenv("PGO_FORCE_COLLECTIVES");
   force_collectives = fc && fc[0] == '1';
   grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
@@ -395,7 +429,8 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(dalloc(&e_my, EL));
   PGOC(dalloc(&e_mt, EL));
   PGOC(dalloc(&e_flags, EL));
-  PGOC(dalloc(&jr, EL * dev::REC));
+  PGOC(dalloc(&jr, EL * rec_doubles));
+  if (info6) PGOC(dalloc(&e_info, 6 * std::max<int64_t>(EL, 1)));
   PGOC(dalloc(&inc_ptr, NL + 1));
   PGOC(dalloc(&inc_edge, S.n_inc));
   PGOC(dalloc(&inc_col, S.n_inc));
@@ -441,6 +476,13 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(upload(e_my, S.my));
   PGOC(upload(e_mt, S.mt));
   PGOC(upload(e_flags, S.flags));
+  if (info6) {  // planes over the local edges
+    std::vector<double> planes((size_t)6 * EL);
+    for (int64_t k = 0; k < EL; ++k)
+      for (int c = 0; c < 6; ++c) planes[(size_t)c * EL + k] = info6[6 * (size_t)S.orig_edge[k] + c];
+    PGOC(upload(e_info, planes));
+    PGOC(sync());  // `planes` dies with this scope
+  }
   PGOC(upload(inc_ptr, S.inc_ptr));
   PGOC(upload(inc_edge, S.inc_edge));
   PGOC(upload(inc_col, S.inc_col));
@@ -925,6 +967,12 @@ void pgo_options_default(pgo_options* o) {
 
 int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
                const double* meas, const uint8_t* kind, const pgo_options* opt, pgo_comm* comm, int device) {
+  return pgo_create_weighted(h, n_poses, poses, n_edges, ia, ib, meas, nullptr, kind, opt, comm, device);
+}
+
+int pgo_create_weighted(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia,
+                        const int32_t* ib, const double* meas, const double* info6_or_null, const uint8_t* kind,
+                        const pgo_options* opt, pgo_comm* comm, int device) {
   if (!h || !poses || n_poses <= 0 || n_edges < 0 || (n_edges && (!ia || !ib || !meas || !kind)))
     return fail(PGO_ERR_INVALID_ARG, "pgo_create: bad argument");
   pgo_options o;
@@ -938,7 +986,7 @@ int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges,
   H->opt = o;
   H->comm = comm;
   H->device = device;
-  PGOC(H->create(n_poses, poses, n_edges, ia, ib, meas, kind));
+  PGOC(H->create(n_poses, poses, n_edges, ia, ib, meas, info6_or_null, kind));
   *h = H.release();
   return PGO_OK;
 }
@@ -946,8 +994,8 @@ int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges,
 int pgo_create_from_graph(pgo_t** h, const pgo_graph* g, const pgo_options* opt, pgo_comm* comm, int device) {
   if (!g) return fail(PGO_ERR_INVALID_ARG, "pgo_create_from_graph: null graph");
   const pgo::Graph& G = g->g;
-  return pgo_create(h, G.n_poses(), G.pose.data(), G.n_edges(), G.ea.data(), G.eb.data(), G.meas.data(), G.kind.data(), opt,
-                    comm, device);
+  return pgo_create_weighted(h, G.n_poses(), G.pose.data(), G.n_edges(), G.ea.data(), G.eb.data(), G.meas.data(),
+                             G.info.size() == (size_t)6 * G.n_edges() ? G.info.data() : nullptr, G.kind.data(), opt, comm, device);
 }
 
 void pgo_destroy(pgo_t* h) { delete h; }
@@ -1030,12 +1078,13 @@ int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss, double* cost
   if (cost) *cost = h->h_scal[0];
   if (want_jac) {
     const int64_t EL = h->S.n_edges_local;
-    std::vector<double> rec((size_t)EL * dev::REC);
+    const int RN = h->rec_doubles, R0 = h->info_mode ? 12 : 10;
+    std::vector<double> rec((size_t)EL * RN);
     HIPC(hipMemcpyAsync(rec.data(), h->jr, rec.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     PGOC(h->sync());
     for (int64_t k = 0; k < EL; ++k) {
       const int64_t e = h->S.orig_edge[k];
-      const double* R = &rec[(size_t)k * dev::REC];
+      const double* R = &rec[(size_t)k * RN];
       if (J_out) {  // expand the implied second block: d e/d P2 = [-A[:,0] | -A[:,1] | (0,0,g2)']
         double* Jo = J_out + 18 * e;
         for (int i = 0; i < 3; ++i) {
@@ -1044,14 +1093,54 @@ int pgo_eval(pgo_t* h, const double* poses_or_null, int apply_loss, double* cost
           Jo[6 * i + 2] = R[3 * i + 2];
           Jo[6 * i + 3] = -R[3 * i];
           Jo[6 * i + 4] = -R[3 * i + 1];
-          Jo[6 * i + 5] = (i == 2) ? R[9] : 0.0;
+          Jo[6 * i + 5] = h->info_mode ? R[9 + i] : ((i == 2) ? R[9] : 0.0);
         }
       }
-      if (r_out) memcpy(r_out + 3 * e, R + 10, 3 * sizeof(double));
+      if (r_out) memcpy(r_out + 3 * e, R + R0, 3 * sizeof(double));
     }
   }
   if (h->h_scal[1] > 0.0) return fail(PGO_ERR_NUMERIC, "non-finite residual or Jacobian");
   return PGO_OK;
+}
+
+int pgo_edge_chi2(pgo_t* h, const double* poses_or_null, double* chi2_out) {
+  if (!h || !chi2_out) return fail(PGO_ERR_INVALID_ARG, "pgo_edge_chi2: null");
+  if (!h->e_info) return fail(PGO_ERR_INVALID_ARG, "pgo_edge_chi2: the handle was created without information matrices");
+  HIPC(hipSetDevice(h->device));
+  const int64_t E = h->n_edges_total, EL = h->S.n_edges_local;
+  if (E == 0) return PGO_OK;
+  if (!h->chi2_buf) {
+    PGOC(h->dalloc(&h->chi2_buf, E));
+    PGOC(h->dalloc(&h->e_orig, std::max<int64_t>(EL, 1)));
+    PGOC(h->upload(h->e_orig, h->S.orig_edge));
+  }
+  const double* x = h->poses;
+  std::vector<double> tmp;
+  if (poses_or_null) {
+    const double* src = poses_or_null;
+    if (!h->perm.empty()) {
+      h->to_internal(poses_or_null, &tmp, 3);
+      src = tmp.data();
+    }
+    HIPC(hipMemcpyAsync(h->cand, src, (size_t)3 * h->S.n_poses * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    PGOC(h->sync());
+    x = h->cand;
+  }
+  HIPC(hipMemsetAsync(h->chi2_buf, 0, (size_t)E * sizeof(double), h->stream));
+  if (EL > 0) {
+    dev::EdgeArgs A = h->edge_args(x, nullptr, 0);
+    const int grid = (int)std::min<int64_t>((EL + dev::WG - 1) / dev::WG, 8192);
+    hipLaunchKernelGGL(dev::k_edge_chi2, dim3(grid), dim3(dev::WG), 0, h->stream, A, (const int32_t*)h->e_orig, h->chi2_buf);
+    PGOC(h->check_launch("k_edge_chi2"));
+  }
+  if (h->multi_rank()) {  // every edge is counted on exactly one rank (flags bit1): the sum assembles the vector
+    for (int64_t off = 0; off < E; off += (1 << 16)) {  // 512 KiB pieces (fits a slot of the shm test back-end)
+      const int n = (int)std::min<int64_t>(E - off, 1 << 16);
+      if (h->comm->allreduce(h->chi2_buf + off, n, false, h->stream) != 0) return fail(PGO_ERR_COMM, "pgo_edge_chi2: all-reduce failed");
+    }
+  }
+  HIPC(hipMemcpyAsync(chi2_out, h->chi2_buf, (size_t)E * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return h->sync();
 }
 
 int pgo_lm_begin(pgo_t* h) {
