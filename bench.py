@@ -37,7 +37,9 @@ def main():
     ap.add_argument("--poses", type=int, default=1_000_000)
     ap.add_argument("--pcg-rtol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=500)
-    ap.add_argument("--pcg-block-poses", type=int, default=4, help="poses per block-Jacobi block (GPU and CPU baseline)")
+    ap.add_argument("--pcg-block-poses", type=int, default=0, help="poses per dense block-Jacobi block, 0 = auto (GPU and CPU baseline)")
+    ap.add_argument("--pcg-chain-len", type=int, default=-1,
+                    help="chain (block-tridiagonal) preconditioner over segments of 64 poses: 64 = on, 0 = off, -1 = auto (GPU and CPU baseline)")
     ap.add_argument("--halo-exchange", type=int, default=1, help="N > 1: 1 = point-to-point halo exchange of the search direction, 0 = all-gather")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--cpu-iters", type=int, default=4, help="LM iterations of the CPU baseline sample (0 = skip)")
@@ -94,8 +96,13 @@ def main():
     t_gen = time.time() - t_gen
     K, W = args.steps, args.warmup
     opt = P.Options(method=1, max_iters=W + K, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0, pcg_rtol=args.pcg_rtol,
-                    pcg_max_iters=args.pcg_max_iters, pcg_block_poses=args.pcg_block_poses, halo_exchange=args.halo_exchange,
+                    pcg_max_iters=args.pcg_max_iters, pcg_block_poses=args.pcg_block_poses, pcg_chain_len=args.pcg_chain_len,
+                    halo_exchange=args.halo_exchange,
                     pcg_check_every=min(100, max(1, args.pcg_max_iters)), verbose=args.verbose if rank == 0 else 0)
+    # the preconditioner the library resolves for these options (pgo_internal.h resolve_chain_len / resolve_block_poses)
+    chain = args.pcg_chain_len if args.pcg_chain_len >= 0 else (64 if (args.pcg_block_poses <= 0 and g.n_poses > 8192) else 0)
+    blockp = args.pcg_block_poses if args.pcg_block_poses > 0 else (32 if g.n_poses <= 8192 else 4)
+    precond = ("block-tridiagonal 64-pose chain segments" if chain else "dense %d-pose blocks" % blockp)
     t_create = time.time()
     s = P.Solver(g, opt, comm, device=local_rank)
     t_create = time.time() - t_create
@@ -144,9 +151,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "synthetic Manhattan world, %d poses / %d edges (%d odometry, %d closure, %d bogus = 10%% "
-                            "outlier loops), DCS on, Huber 0.01, LM (Ceres policy) + block-Jacobi (%d-pose blocks) PCG rtol %.g <= %d it"
+                            "outlier loops), DCS on, Huber 0.01, LM (Ceres policy) + block-Jacobi (%s) PCG rtol %.g <= %d it"
                             % (g.n_poses, n_edges, g.n_edges_of_kind(0), g.n_edges_of_kind(1), g.n_edges_of_kind(2),
-                               args.pcg_block_poses, args.pcg_rtol, args.pcg_max_iters),
+                               precond, args.pcg_rtol, args.pcg_max_iters),
                 "baseline_config": "configs[4] (synthetic 1M poses / ~4M edges, 10% outliers, sharded PCG)",
                 "parallelism": "pose-id range shards x%d%s" % (world, "" if world == 1 else (", halo exchange" if args.halo_exchange else ", all-gather")),
                 "seed": 20260410,
@@ -191,7 +198,7 @@ def main():
                          np.array(g.info), np.array(g.kind))
             oo = O.Options(method=1, max_iters=args.cpu_iters, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0,
                            pcg_rtol=args.pcg_rtol, pcg_max_iters=args.pcg_max_iters, threads=threads,
-                           pcg_block_poses=args.pcg_block_poses)
+                           pcg_block_poses=blockp, pcg_chain_len=chain)
             tc = time.perf_counter()
             ores = O.lm_pcg(og, oo)
             tc = time.perf_counter() - tc

@@ -167,7 +167,12 @@ typedef struct pgo_options {
                                   (differentiated through s, as the reference differentiates through psi).  Needs the
                                   information matrices (pgo_create_weighted / pgo_create_from_graph), all positive
                                   definite; METHOD 2: PGO_ERR_UNSUPPORTED                                            */
-  int32_t reserved[2];
+  int32_t pcg_chain_len;       /* chain preconditioner: block-Jacobi over segments of 64 consecutive poses whose blocks are
+                                  kept block-TRIDIAGONAL (the odometry chain inside the segment; every other edge only
+                                  adds its 3x3 diagonal blocks), factorised exactly per LM iteration and applied by two
+                                  wavefront scans.  64 = on (overrides pcg_block_poses), 0 = off,
+                                  -1 (default) = on when pcg_block_poses is 0 (auto) and the graph has > 8192 poses     */
+  int32_t reserved[1];
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */
@@ -286,6 +291,7 @@ typedef struct pgo_kernel_stats {
 int pgo_bench_eval(pgo_t* h, int reps, int with_jacobian, pgo_kernel_stats* out); /* [gpu] K1 */
 int pgo_bench_assemble(pgo_t* h, int reps, pgo_kernel_stats* out);                /* [gpu] K2 */
 int pgo_bench_spmv(pgo_t* h, int reps, pgo_kernel_stats* out);                    /* [gpu] K3 */
+int pgo_bench_precond(pgo_t* h, int reps, pgo_kernel_stats* out);                 /* [gpu] z = M^-1 b as the PCG start-up kernel */
 /* y = (J'J + D'D) x in the scaled space at the current linearisation, with the
  * current LM diagonal; x,y: 3N doubles (world == 1).  For SpMV parity tests.    */
 int pgo_debug_spmv(pgo_t* h, const double* x, double* y);                         /* [gpu] */

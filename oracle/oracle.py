@@ -43,7 +43,7 @@ class _Opts(C.Structure):
                [(n, C.c_double) for n in ("phi", "huber_delta", "ftol", "gtol", "ptol", "radius0", "max_radius",
                                           "min_radius", "min_relative_decrease", "min_lm_diagonal",
                                           "max_lm_diagonal", "pcg_rtol")] + \
-               [(n, C.c_int32) for n in ("pcg_max_iters", "threads", "verbose", "block_poses")]
+               [(n, C.c_int32) for n in ("pcg_max_iters", "threads", "verbose", "block_poses", "chain_len", "_pad")]
 
 
 class _Iter(C.Structure):
@@ -321,6 +321,7 @@ class Options:
     threads: int = 1
     verbose: int = 0
     pcg_block_poses: int = 1   # lm_pcg only: poses per block-Jacobi block
+    pcg_chain_len: int = 0     # lm_pcg only: > 0 = chain (block-tridiagonal) preconditioner over segments of this many poses
     info_weighting: int = 0    # 1: whitened residuals + chi2 DCS (optional mode, see pgo_oracle.c edge_functor_jet)
 
 
@@ -495,7 +496,7 @@ def lm_pcg(g: Graph, opt: Options = Options()) -> Result:
     o = _Opts(opt.method, opt.max_iters, opt.fixed_pose, opt.jacobi_scaling, opt.phi, opt.huber_delta, opt.ftol,
               opt.gtol, opt.ptol, opt.radius0, opt.max_radius, opt.min_radius, opt.min_relative_decrease,
               opt.min_lm_diagonal, opt.max_lm_diagonal, opt.pcg_rtol, opt.pcg_max_iters, opt.threads, opt.verbose,
-              opt.pcg_block_poses)
+              opt.pcg_block_poses, opt.pcg_chain_len, 0)
     cap = opt.max_iters + 2
     recs = (_Iter * cap)()
     nrec = C.c_int(0)

@@ -473,6 +473,9 @@ typedef struct {
   double phi, huber_delta, ftol, gtol, ptol, radius0, max_radius, min_radius, min_relative_decrease, min_lm_diagonal,
       max_lm_diagonal, pcg_rtol;
   int32_t pcg_max_iters, threads, verbose, block_poses; /* block_poses: poses per block-Jacobi block (<=1: 3x3) */
+  int32_t chain_len, _pad; /* > 0: block-Jacobi over segments of chain_len consecutive poses whose blocks are kept
+                              block-TRIDIAGONAL (the odometry chain inside the segment; every other edge only adds to
+                              the 3x3 diagonal blocks), solved exactly by a block LDL' sweep; overrides block_poses */
 } oracle_options;
 
 typedef struct {
@@ -505,6 +508,9 @@ typedef struct {
   double* D2;   /* 3N */
   int B;        /* poses per preconditioner block; > 1: dense Cholesky factors in Lg */
   double* Lg;   /* n_groups x nb x nb (lower Cholesky factors), nb = 3B */
+  int chain;    /* > 0: chain preconditioner with segments of this many poses */
+  double* Cw;   /* N x 9: W_i = C_i S_{i-1}^-1 (C_i = the block (i, i-1) of H; 0 at a segment start) */
+  double* Cs;   /* N x 9: S_i^-1,  S_i = (H_ii + D2_i) - W_i C_i' */
 } normal_eq;
 
 static void build_incidence(normal_eq* Q) {
@@ -544,6 +550,8 @@ static void free_normal_eq(normal_eq* Q) {
   free(Q->Minv);
   free(Q->D2);
   free(Q->Lg);
+  free(Q->Cw);
+  free(Q->Cs);
 }
 
 /* H = (J S)^T (J S), gs = S J^T r ; s: 3N column scales (0 on the fixed pose) */
@@ -662,6 +670,69 @@ static void apply_groups(const normal_eq* Q, const double* r, double* z, int thr
   }
 }
 
+/* Chain preconditioner: M = block-tridiagonal part of (H + D2) inside segments of Q->chain consecutive poses
+ * (= sum of J'J over the edges joining consecutive poses of a segment + the 3x3 diagonal blocks of every other edge
+ * + D2, hence SPD).  Block LDL': S_i = M_ii - W_i C_i', W_i = C_i S_{i-1}^-1.                                      */
+static void factor_chain(normal_eq* Q, int threads) {
+  int N = Q->N, L = Q->chain, ns = (N + L - 1) / L;
+  if (!Q->Cw) Q->Cw = (double*)malloc((size_t)N * 9 * sizeof(double));
+  if (!Q->Cs) Q->Cs = (double*)malloc((size_t)N * 9 * sizeof(double));
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+  for (int sgm = 0; sgm < ns; ++sgm) {
+    int s0 = sgm * L, s1 = s0 + L < N ? s0 + L : N;
+    for (int i = s0; i < s1; ++i) {
+      double M[9], C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double* W = Q->Cw + 9 * (size_t)i;
+      for (int k = 0; k < 9; ++k) M[k] = Q->Hd[9 * (size_t)i + k];
+      for (int a = 0; a < 3; ++a) M[4 * a] += Q->D2[3 * (size_t)i + a];
+      if (i > s0) {
+        for (int q = Q->inc_ptr[i]; q < Q->inc_ptr[i + 1]; ++q)
+          if (Q->inc_col[q] == i - 1)
+            for (int k = 0; k < 9; ++k) C[k] += Q->Hoff[9 * (size_t)q + k];
+        const double* Sp = Q->Cs + 9 * (size_t)(i - 1);
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) W[3 * a + b] = C[3 * a] * Sp[b] + C[3 * a + 1] * Sp[3 + b] + C[3 * a + 2] * Sp[6 + b];
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) M[3 * a + b] -= W[3 * a] * C[3 * b] + W[3 * a + 1] * C[3 * b + 1] + W[3 * a + 2] * C[3 * b + 2];
+      } else {
+        for (int k = 0; k < 9; ++k) W[k] = 0.0;
+      }
+      /* S is symmetric in exact arithmetic: keep the upper triangle */
+      M[3] = M[1];
+      M[6] = M[2];
+      M[7] = M[5];
+      inv3_sym(M, Q->Cs + 9 * (size_t)i);
+    }
+  }
+}
+
+static void apply_chain(const normal_eq* Q, const double* r, double* z, int threads) {
+  int N = Q->N, L = Q->chain, ns = (N + L - 1) / L;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+  for (int sgm = 0; sgm < ns; ++sgm) {
+    int s0 = sgm * L, s1 = s0 + L < N ? s0 + L : N;
+    double t[3] = {0, 0, 0};
+    for (int i = s0; i < s1; ++i) { /* t_i = r_i - W_i t_{i-1};  z_i <- S_i^-1 t_i */
+      const double *W = Q->Cw + 9 * (size_t)i, *Si = Q->Cs + 9 * (size_t)i;
+      double v[3];
+      for (int a = 0; a < 3; ++a) v[a] = r[3 * (size_t)i + a] - (W[3 * a] * t[0] + W[3 * a + 1] * t[1] + W[3 * a + 2] * t[2]);
+      for (int a = 0; a < 3; ++a) {
+        t[a] = v[a];
+      }
+      for (int a = 0; a < 3; ++a) z[3 * (size_t)i + a] = Si[3 * a] * v[0] + Si[3 * a + 1] * v[1] + Si[3 * a + 2] * v[2];
+    }
+    for (int i = s1 - 2; i >= s0; --i) { /* z_i -= W_{i+1}' z_{i+1} */
+      const double* W = Q->Cw + 9 * (size_t)(i + 1);
+      const double* zn = z + 3 * (size_t)(i + 1);
+      for (int a = 0; a < 3; ++a) z[3 * (size_t)i + a] -= W[a] * zn[0] + W[3 + a] * zn[1] + W[6 + a] * zn[2];
+    }
+  }
+}
+
 /* y = (H + D2) x */
 static void spmv(const normal_eq* Q, const double* x, double* y, int with_d2, int threads) {
   int N = Q->N;
@@ -698,6 +769,10 @@ static double dot(const double* a, const double* b, size_t n, int threads) {
 
 static void apply_minv(const normal_eq* Q, const double* r, double* z, int threads) {
   int N = Q->N;
+  if (Q->chain > 0) {
+    apply_chain(Q, r, z, threads);
+    return;
+  }
   if (Q->B > 1) {
     apply_groups(Q, r, z, threads);
     return;
@@ -768,6 +843,7 @@ int pgo_oracle_lm_pcg_w(int N, double* poses, int E, const int32_t* ia, const in
   Q.ia = ia;
   Q.ib = ib;
   Q.B = (o->block_poses > 1) ? (o->block_poses > 32 ? 32 : o->block_poses) : 1;
+  Q.chain = o->chain_len > 0 ? o->chain_len : 0;
   build_incidence(&Q);
   double* r = (double*)malloc((size_t)E * 3 * sizeof(double));
   double* J = (double*)malloc((size_t)E * 18 * sizeof(double));
@@ -860,7 +936,8 @@ int pgo_oracle_lm_pcg_w(int N, double* poses, int E, const int32_t* ia, const in
       }
       inv3_sym(A, Q.Minv + 9 * (size_t)i);
     }
-    if (Q.B > 1) factor_groups(&Q, threads);
+    if (Q.chain > 0) factor_chain(&Q, threads);
+    else if (Q.B > 1) factor_groups(&Q, threads);
     t0 = now_s();
     double rel = 0.0;
     int k = pcg(&Q, gs, y, o->pcg_rtol, o->pcg_max_iters, &rel, w, threads);

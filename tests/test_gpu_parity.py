@@ -282,6 +282,49 @@ def test_lm_inexact_matches_port_on_synthetic_10k(pgo, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("n_poses,seed", [(10000, 20260410), (30011, 3)])
+def test_chain_preconditioner_matches_port(pgo, oracle, n_poses, seed):
+    """pcg_chain_len = 64: block-tridiagonal segments, factor (k_chain_factor) + wave-scan apply (k_cg_update1_c) against
+    the sequential block LDL' sweep of the C port: same LM history, PCG iteration counts within 1, and fewer PCG
+    iterations than the dense 4-pose blocks.  30011 poses: the last segment is short (ragged)."""
+    g = pgo.synth_manhattan(n_poses, 4.0, 0.10, seed)
+    og = oracle_graph(oracle, g)
+    kw = dict(method=1, max_iters=6, pcg_rtol=0.1, pcg_max_iters=500)
+    s = pgo.Solver(g, pgo.Options(pcg_chain_len=64, **kw))
+    summ = s.solve()
+    ores = oracle.lm_pcg(og, oracle.Options(threads=8, pcg_chain_len=64, **kw))
+    recs = s.iter_records()
+    assert len(recs) == len(ores.records)
+    for a, b in zip(recs, ores.records):
+        assert a["step_ok"] == b["step_ok"]
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-9)
+        assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 1
+    assert np.abs(s.poses() - ores.poses).max() < 1e-7
+    s4 = pgo.Solver(g, pgo.Options(pcg_block_poses=4, **kw))
+    summ4 = s4.solve()
+    print(f"PCG iterations over 6 LM iterations, {n_poses} poses: chain-64 {summ.total_pcg_iters}, 4-pose blocks {summ4.total_pcg_iters}")
+    assert summ.total_pcg_iters < summ4.total_pcg_iters
+    s.close(); s4.close()
+
+
+@pytest.mark.parametrize("name,n_out,method", [("INTEL", 50, 1), ("M3500", 0, 0), ("MIT", 0, 1)])
+def test_chain_preconditioner_exact_mode_matches_golden(pgo, name, n_out, method):
+    """the preconditioner must not change WHAT is solved: tight PCG with the chain preconditioner reproduces the
+    direct-solve fixtures like the dense blocks do"""
+    tag = "%s_out%d_m%d" % (name, n_out, method)
+    fx = json.load(open(os.path.join(GOLDEN, "lm_%s.json" % tag)))
+    ref = np.load(os.path.join(GOLDEN, "lm_%s_poses.npy" % tag))
+    g = load(pgo, name, n_out)
+    s = pgo.Solver(g, pgo.Options(method=method, pcg_chain_len=64, pcg_max_iters=400000))
+    summ = s.solve()
+    d_xy = np.abs(s.poses()[:, :2] - ref[:, :2]).max()
+    print(f"{tag} chain-64: max |d translation| {d_xy:.3e}  pcg iters {summ.total_pcg_iters}  {summ.seconds_total:.2f} s")
+    assert summ.termination == fx["termination"] and summ.iterations == fx["iterations"]
+    assert summ.final_cost == pytest.approx(fx["final_cost"], rel=1e-7)
+    assert d_xy < 5e-6
+    s.close()
+
+
 def test_bitwise_reproducible(pgo):
     g = pgo.synth_manhattan(50000, 4.0, 0.10, 5)
     out = []

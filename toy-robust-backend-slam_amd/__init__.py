@@ -39,7 +39,7 @@ EXPORTS = [
     "pgo_create", "pgo_create_weighted", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_edge_chi2", "pgo_solve", "pgo_lm_begin", "pgo_lm_step",
     "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
     "pgo_write_switches",
-    "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_debug_spmv", "pgo_debug_normal_eq",
+    "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_bench_precond", "pgo_debug_spmv", "pgo_debug_normal_eq",
     "pgo_shard_plan", "pgo_shard_halo", "pgo_pose_order",
 ]
 
@@ -60,7 +60,7 @@ class Options(C.Structure):
                 ("max_lm_diagonal", C.c_double), ("pcg_rtol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("pcg_check_every", C.c_int32), ("verbose", C.c_int32),
                 ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("sc_prior_lambda", C.c_double), ("pose_ordering", C.c_int32), ("info_weighting", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("pcg_chain_len", C.c_int32), ("reserved", C.c_int32 * 1)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -169,6 +169,7 @@ def lib():
     L.pgo_bench_eval.argtypes = [vp, C.c_int, C.c_int, C.POINTER(KernelStats)]
     L.pgo_bench_assemble.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
     L.pgo_bench_spmv.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
+    L.pgo_bench_precond.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
     L.pgo_debug_spmv.argtypes = [vp, dp, dp]
     L.pgo_debug_normal_eq.argtypes = [vp, dp, dp]
     L.pgo_shard_plan.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
@@ -484,4 +485,9 @@ class Solver:
     def bench_spmv(self, reps=10) -> KernelStats:
         k = KernelStats()
         _check(lib().pgo_bench_spmv(self._h, reps, C.byref(k)))
+        return k
+
+    def bench_precond(self, reps=10) -> KernelStats:
+        k = KernelStats()
+        _check(lib().pgo_bench_precond(self._h, reps, C.byref(k)))
         return k

@@ -1066,6 +1066,243 @@ __global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int pa
   }
 }
 
+// ------------------------------------------------- chain (block-tridiagonal) preconditioner
+// Block-Jacobi over segments of CHAIN = 64 consecutive poses (one wavefront) whose blocks are kept block-TRIDIAGONAL:
+//     M_seg = sum of J'J over the edges joining consecutive poses of the segment (the odometry chain)
+//             + the 3x3 diagonal blocks of every other edge + D'D          (a sum of PSD terms + D'D: SPD)
+// i.e. the block-tridiagonal part of (H + D'D) inside the segment.  Factorised once per LM iteration as block LDL'
+//     S_i = M_ii - W_i C_i',   W_i = C_i S_{i-1}^-1,   C_i = H_{i,i-1}
+// (k_chain_factor, one thread per segment) and applied as  t_i = r_i - W_i t_{i-1};  z_i = S_i^-1 t_i - W_{i+1}' z_{i+1}.
+// Both recurrences are affine maps composed along the segment, so the apply is two wave-level scans (lane = pose,
+// 6 shuffle levels each) fused into the CG update kernels: 120 B/pose of factors per PCG iteration instead of the
+// 288 B/pose of the dense 4-pose blocks, and 20-60 % fewer PCG iterations on the 1M-pose graph.
+constexpr int CHAIN = 64;
+
+struct ChainPre {
+  const double* cw;   // 9 planes [n_loc]: W_i, row-major 3x3 (0 at a segment start)
+  const double* cs;   // 6 planes [n_loc]: S_i^-1 (00 01 02 11 12 22)
+  int32_t n_loc;
+};
+
+// C_i: sum of the off-diagonal blocks (i, i-1) of row i (9 planes); 0 at a segment start
+__global__ void k_chain_extract(const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_col,
+                                const double* __restrict__ hoff, int n_loc, int lo, double* __restrict__ cc) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_loc) return;
+  double acc[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if ((row & (CHAIN - 1)) != 0) {
+    const int target = lo + row - 1;
+    for (int q = inc_ptr[row]; q < inc_ptr[row + 1]; ++q)
+      if (inc_col[q] == target) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) acc[c] += hoff[hoff_index(c, q)];
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) cc[(int64_t)c * n_loc + row] = acc[c];
+}
+
+// one thread per segment, sequential along the chain (64 dependent 3x3 steps; once per LM iteration)
+__global__ void k_chain_factor(const double* __restrict__ hd, const double* __restrict__ d2, const double* __restrict__ cc,
+                               int n_loc, double* __restrict__ cw, double* __restrict__ cs) {
+  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = n_loc;
+  const int64_t s0 = (int64_t)seg * CHAIN;
+  if (s0 >= n) return;
+  const int64_t s1 = s0 + CHAIN < n ? s0 + CHAIN : n;
+  double p00 = 0.0, p01 = 0.0, p02 = 0.0, p11 = 0.0, p12 = 0.0, p22 = 0.0;  // S_{i-1}^-1
+  for (int64_t i = s0; i < s1; ++i) {
+    double a00 = hd[i] + d2[3 * i], a01 = hd[n + i], a02 = hd[2 * n + i], a11 = hd[3 * n + i] + d2[3 * i + 1],
+           a12 = hd[4 * n + i], a22 = hd[5 * n + i] + d2[3 * i + 2];
+    double W[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (i > s0) {
+      double C[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) C[c] = cc[(int64_t)c * n + i];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {  // W = C S_{i-1}^-1
+        W[3 * a] = C[3 * a] * p00 + C[3 * a + 1] * p01 + C[3 * a + 2] * p02;
+        W[3 * a + 1] = C[3 * a] * p01 + C[3 * a + 1] * p11 + C[3 * a + 2] * p12;
+        W[3 * a + 2] = C[3 * a] * p02 + C[3 * a + 1] * p12 + C[3 * a + 2] * p22;
+      }
+      // S = M - W C'  (upper triangle; symmetric in exact arithmetic)
+      a00 -= W[0] * C[0] + W[1] * C[1] + W[2] * C[2];
+      a01 -= W[0] * C[3] + W[1] * C[4] + W[2] * C[5];
+      a02 -= W[0] * C[6] + W[1] * C[7] + W[2] * C[8];
+      a11 -= W[3] * C[3] + W[4] * C[4] + W[5] * C[5];
+      a12 -= W[3] * C[6] + W[4] * C[7] + W[5] * C[8];
+      a22 -= W[6] * C[6] + W[7] * C[7] + W[8] * C[8];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) cw[(int64_t)c * n + i] = W[c];
+    const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+    const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
+    p00 = c00 * id;
+    p01 = c01 * id;
+    p02 = c02 * id;
+    p11 = (a00 * a22 - a02 * a02) * id;
+    p12 = (a01 * a02 - a00 * a12) * id;
+    p22 = (a00 * a11 - a01 * a01) * id;
+    cs[i] = p00;
+    cs[n + i] = p01;
+    cs[2 * n + i] = p02;
+    cs[3 * n + i] = p11;
+    cs[4 * n + i] = p12;
+    cs[5 * n + i] = p22;
+  }
+}
+
+// a += M b ; then (optionally) M <- M N    (3x3 row-major)
+__device__ __forceinline__ void affine_compose(double a[3], double M[9], const double b[3], const double N[9], bool with_m) {
+  a[0] += M[0] * b[0] + M[1] * b[1] + M[2] * b[2];
+  a[1] += M[3] * b[0] + M[4] * b[1] + M[5] * b[2];
+  a[2] += M[6] * b[0] + M[7] * b[1] + M[8] * b[2];
+  if (with_m) {
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[3 * i + j] = M[3 * i] * N[j] + M[3 * i + 1] * N[3 + j] + M[3 * i + 2] * N[6 + j];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) M[c] = R[c];
+  }
+}
+
+// z = M_seg^-1 r for the segment held by this wavefront (lane = pose).  Every lane of the wave must call it;
+// lanes with !valid pass zeros.  row = local row of this lane.
+// ABL != 0: timing-only ablations used by pgo_bench_precond (1: no backward scan, 2: no scans) -- wrong results.
+template <int ABL = 0>
+__device__ __forceinline__ void chain_apply(const ChainPre& C, int64_t row, bool valid, double r0, double r1, double r2,
+                                            double& z0, double& z1, double& z2) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = C.n_loc;
+  double a[3] = {r0, r1, r2}, M[9];
+  const bool has_prev = valid && lane > 0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) M[c] = has_prev ? -C.cw[(int64_t)c * n + row] : 0.0;
+  // forward: t_i = r_i - W_i t_{i-1}  (inclusive scan of affine maps, Hillis-Steele)
+#pragma unroll
+  for (int off = 1; off < (ABL >= 2 ? 1 : 64); off <<= 1) {
+    double b[3], N[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[k] = __shfl_up(a[k], off, 64);
+    if (off < 32) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) N[c] = __shfl_up(M[c], off, 64);
+    }
+    if (lane >= off) affine_compose(a, M, b, N, off < 32);
+  }
+  // u = S^-1 t
+  double u[3] = {0.0, 0.0, 0.0};
+  if (valid) {
+    const double s00 = C.cs[row], s01 = C.cs[n + row], s02 = C.cs[2 * n + row], s11 = C.cs[3 * n + row],
+                 s12 = C.cs[4 * n + row], s22 = C.cs[5 * n + row];
+    u[0] = s00 * a[0] + s01 * a[1] + s02 * a[2];
+    u[1] = s01 * a[0] + s11 * a[1] + s12 * a[2];
+    u[2] = s02 * a[0] + s12 * a[1] + s22 * a[2];
+  }
+  // backward: z_i = u_i - W_{i+1}' z_{i+1}
+  const bool has_next = valid && lane < 63 && row + 1 < n;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) M[3 * i + j] = has_next ? -C.cw[(int64_t)(3 * j + i) * n + row + 1] : 0.0;
+#pragma unroll
+  for (int off = 1; off < (ABL >= 1 ? 1 : 64); off <<= 1) {
+    double b[3], N[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[k] = __shfl_down(u[k], off, 64);
+    if (off < 32) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) N[c] = __shfl_down(M[c], off, 64);
+    }
+    if (lane + off < 64) affine_compose(u, M, b, N, off < 32);
+  }
+  z0 = u[0];
+  z1 = u[1];
+  z2 = u[2];
+}
+
+template <int ABL>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cg_init_c(CgVec V, ChainPre C, const double* __restrict__ b,
+                                                  double* __restrict__ part_rz, double* __restrict__ part_bb) {
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  const int64_t n = V.n_loc;
+  double rz = 0.0, bb = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * WG; base < n; base += (int64_t)gridDim.x * WG) {
+    const int64_t row = base + tid;
+    const bool valid = row < n;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, z0, z1, z2;
+    if (valid) {
+      r0 = b[3 * row];
+      r1 = b[3 * row + 1];
+      r2 = b[3 * row + 2];
+    }
+    chain_apply<ABL>(C, row, valid, r0, r1, r2, z0, z1, z2);
+    if (valid) {
+      double* y = V.y + 3 * row;
+      double* r = V.r + 3 * row;
+      double* z = V.z + 3 * row;
+      double* p = V.p + 3 * ((int64_t)V.lo + row);
+      y[0] = 0.0; y[1] = 0.0; y[2] = 0.0;
+      r[0] = r0; r[1] = r1; r[2] = r2;
+      z[0] = z0; z[1] = z1; z[2] = z2;
+      p[0] = z0; p[1] = z1; p[2] = z2;
+      rz += r0 * z0 + r1 * z1 + r2 * z2;
+      bb += r0 * r0 + r1 * r1 + r2 * r2;
+    }
+  }
+  rz = block_sum_bcast(rz, red);
+  bb = block_sum_bcast(bb, red);
+  if (tid == 0) {
+    part_rz[blockIdx.x] = rz;
+    part_bb[blockIdx.x] = bb;
+  }
+}
+
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cg_update1_c(CgVec V, ChainPre C, int parity, const double* __restrict__ part_pap,
+                                                     int n_pap, double* __restrict__ part_rz, double* __restrict__ part_rr) {
+  __shared__ double red[8];
+  if (V.st->done) return;
+  const int tid = threadIdx.x;
+  const double pap = sum_partials_bcast(part_pap, n_pap, red);
+  const double alpha = V.st->rz[parity] / pap;
+  const int64_t n = V.n_loc;
+  double rz = 0.0, rr = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * WG; base < n; base += (int64_t)gridDim.x * WG) {
+    const int64_t row = base + tid;
+    const bool valid = row < n;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, z0, z1, z2;
+    if (valid) {
+      double* y = V.y + 3 * row;
+      double* r = V.r + 3 * row;
+      const double* p = V.p + 3 * ((int64_t)V.lo + row);
+      const double* ap = V.ap + 3 * row;
+      y[0] += alpha * p[0];
+      y[1] += alpha * p[1];
+      y[2] += alpha * p[2];
+      r0 = r[0] - alpha * ap[0];
+      r1 = r[1] - alpha * ap[1];
+      r2 = r[2] - alpha * ap[2];
+      r[0] = r0; r[1] = r1; r[2] = r2;
+    }
+    chain_apply(C, row, valid, r0, r1, r2, z0, z1, z2);
+    if (valid) {
+      double* z = V.z + 3 * row;
+      z[0] = z0; z[1] = z1; z[2] = z2;
+      rz += r0 * z0 + r1 * z1 + r2 * z2;
+      rr += r0 * r0 + r1 * r1 + r2 * r2;
+    }
+  }
+  rz = block_sum_bcast(rz, red);
+  rr = block_sum_bcast(rr, red);
+  if (tid == 0) {
+    part_rz[blockIdx.x] = rz;
+    part_rr[blockIdx.x] = rr;
+  }
+}
+
 // ------------------------------------------------- METHOD 2: switch variables, eliminated edge by edge
 // A switch s_e appears in exactly two residual blocks (its edge and its prior), so it is eliminated from the LM
 // system exactly (Schur complement per edge).  With sigma = Jacobi scale of the switch column, j = d e / d s,

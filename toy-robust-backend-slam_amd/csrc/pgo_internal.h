@@ -92,6 +92,13 @@ inline int resolve_block_poses(int opt_value, int32_t n_poses) {
   return b > 32 ? 32 : b;
 }
 
+// segment length of the chain (block-tridiagonal) preconditioner for an option value: -1 = auto (64 on graphs of more
+// than 8192 poses when the block size is also left to auto; the small graphs keep their dense 32-pose blocks), 0 = off
+inline int resolve_chain_len(int opt_value, int opt_block_poses, int32_t n_poses) {
+  if (opt_value < 0) return (opt_block_poses <= 0 && n_poses > 8192) ? 64 : 0;
+  return opt_value;
+}
+
 }  // namespace pgo
 
 struct pgo_graph {

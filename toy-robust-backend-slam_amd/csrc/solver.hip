@@ -95,6 +95,9 @@ struct pgo_handle {
   size_t grp_lds = 0;
   int grp_prep_grid = 1;
   double* ginv = nullptr;
+  // chain (block-tridiagonal) preconditioner over 64-pose segments (opt.pcg_chain_len): C planes, W planes, S^-1 planes
+  int chain_len = 0, g_chain = 1;
+  double *chain_c = nullptr, *chain_w = nullptr, *chain_s = nullptr;
   // halo exchange of the search direction (world > 1, opt.halo_exchange)
   bool use_halo = false;
   int32_t *halo_send_rows = nullptr, *halo_recv_rows = nullptr;
@@ -390,6 +393,10 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   const char* fc = getenv("PGO_FORCE_COLLECTIVES");
   force_collectives = fc && fc[0] == '1';
   grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
+  chain_len = pgo::resolve_chain_len(opt.pcg_chain_len, opt.pcg_block_poses, N);
+  if (chain_len != 0 && chain_len != dev::CHAIN)
+    return fail(PGO_ERR_INVALID_ARG, "pcg_chain_len: the device kernels use segments of 64 poses (one wavefront): pass 64, 0 or -1");
+  if (chain_len) grp_B = 1;
   // internal pose numbering
   const bool reorder = opt.pose_ordering == 1 || (opt.pose_ordering < 0 && world > 1);
   std::vector<int32_t> ia_p, ib_p;
@@ -411,7 +418,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     poses_h = poses_p.data();
     if (fixed_internal >= 0) fixed_internal = perm[fixed_internal];
   }
-  PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, grp_B, &S));
+  PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, chain_len ? chain_len : grp_B, &S));
   HIPC(hipSetDevice(device));
   HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   n_full = (int64_t)world * S.rows_per_rank;
@@ -525,6 +532,14 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
                                (int)grp_lds));
   } else {
     grp_B = 1;
+  }
+  if (chain_len && NL > 0) {
+    PGOC(dalloc(&chain_c, 9 * NL));
+    PGOC(dalloc(&chain_w, 9 * NL));
+    PGOC(dalloc(&chain_s, 6 * NL));
+    g_chain = (int)std::min<int64_t>((NL + dev::WG - 1) / dev::WG, 2048);
+  } else {
+    chain_len = 0;
   }
   return sync();
 }
@@ -652,9 +667,14 @@ int pgo_handle::pcg(int* iters, double* rel) {
   GP.nb = grp_nb;
   GP.nb_pad = grp_pad;
   GP.n_groups = n_groups;
-  const bool grouped = grp_B > 1;
-  const int g_u1 = grouped ? g_grp : g_vec;  // grid (= number of partials) of the init / update1 kernels
-  if (grouped) hipLaunchKernelGGL(dev::k_cg_init_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, (const double*)gs, part[0], part[1]);
+  const bool grouped = grp_B > 1, chained = chain_len > 0;
+  dev::ChainPre CP;
+  CP.cw = chain_w;
+  CP.cs = chain_s;
+  CP.n_loc = S.n_loc;
+  const int g_u1 = chained ? g_chain : (grouped ? g_grp : g_vec);  // grid (= number of partials) of the init / update1 kernels
+  if (chained) hipLaunchKernelGGL(dev::k_cg_init_c<0>, dim3(g_u1), dim3(dev::WG), 0, stream, V, CP, (const double*)gs, part[0], part[1]);
+  else if (grouped) hipLaunchKernelGGL(dev::k_cg_init_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, (const double*)gs, part[0], part[1]);
   else hipLaunchKernelGGL(dev::k_cg_init, dim3(g_u1), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
   PGOC(check_launch("k_cg_init"));
   PGOC(reduce_to_scal({{part[0], g_u1, 0}, {part[1], g_u1, 0}}, 4));
@@ -669,7 +689,8 @@ int pgo_handle::pcg(int* iters, double* rel) {
     const double* pap = multi ? scal + 6 : part[0];
     const int n_pap = multi ? 1 : g_spmv;
     if (multi) PGOC(reduce_to_scal({{part[0], g_spmv, 0}}, 6));
-    if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, par, pap, n_pap, part[1], part[2]);
+    if (chained) hipLaunchKernelGGL(dev::k_cg_update1_c, dim3(g_u1), dim3(dev::WG), 0, stream, V, CP, par, pap, n_pap, part[1], part[2]);
+    else if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, par, pap, n_pap, part[1], part[2]);
     else hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_u1), dim3(dev::WG), 0, stream, V, par, pap, n_pap, part[1], part[2]);
     PGOC(check_launch("k_cg_update1"));
     if (multi) {
@@ -769,6 +790,15 @@ int pgo_handle::lm_iteration(bool* stop) {
     GA.n_groups = n_groups;
     hipLaunchKernelGGL(dev::k_prepare_groups, dim3(grp_prep_grid), dim3(dev::WG), grp_lds, stream, GA);
     PGOC(check_launch("k_prepare_groups"));
+  }
+  if (chain_len) {
+    hipLaunchKernelGGL(dev::k_chain_extract, dim3(g_rows), dim3(dev::WG), 0, stream, (const int32_t*)inc_ptr, (const int32_t*)inc_col,
+                       (const double*)hoff, S.n_loc, S.lo, chain_c);
+    PGOC(check_launch("k_chain_extract"));
+    const int n_seg = (S.n_loc + dev::CHAIN - 1) / dev::CHAIN;
+    hipLaunchKernelGGL(dev::k_chain_factor, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)hd, (const double*)d2,
+                       (const double*)chain_c, S.n_loc, chain_w, chain_s);
+    PGOC(check_launch("k_chain_factor"));
   }
   int k_it = 0;
   double rel = 0.0;
@@ -963,6 +993,7 @@ void pgo_options_default(pgo_options* o) {
   o->use_graphs = 1;
   o->sc_prior_lambda = 1.0;
   o->pose_ordering = -1;
+  o->pcg_chain_len = -1;
 }
 
 int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
@@ -1296,6 +1327,49 @@ int pgo_bench_spmv(pgo_t* h, int reps, pgo_kernel_stats* out) {
   // 76 B per off-diagonal block (value + column) ; per row: 48 B diagonal planes + 24 B D'D + 4 B row
   // pointer + 24 B y + 24 B p
   out->algorithmic_bytes = 76.0 * (double)h->S.n_inc + 124.0 * h->S.n_loc;
+  return PGO_OK;
+}
+
+// the preconditioner apply as the PCG start-up kernel issues it (z = M^-1 b; writes y, r, z, p): timing only
+int pgo_bench_precond(pgo_t* h, int reps, pgo_kernel_stats* out) {
+  if (!h || !out || reps < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_precond: bad argument");
+  if (!h->lin_valid || h->iter < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_precond: run at least one LM iteration first");
+  HIPC(hipSetDevice(h->device));
+  dev::CgVec V = h->cg_vec();
+  const char* ab = getenv("PGO_CHAIN_ABLATE");
+  const int abl = ab ? atoi(ab) : 0;
+  double ms = 0;
+  const double nl = (double)h->S.n_loc;
+  if (h->chain_len) {
+    dev::ChainPre CP;
+    CP.cw = h->chain_w;
+    CP.cs = h->chain_s;
+    CP.n_loc = h->S.n_loc;
+    PGOC(time_launches(h, reps, [&] {
+      if (abl == 1) hipLaunchKernelGGL(dev::k_cg_init_c<1>, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->gs, h->part[0], h->part[1]);
+      else if (abl == 2) hipLaunchKernelGGL(dev::k_cg_init_c<2>, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->gs, h->part[0], h->part[1]);
+      else hipLaunchKernelGGL(dev::k_cg_init_c<0>, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->gs, h->part[0], h->part[1]);
+    }, &ms));
+    out->algorithmic_bytes = (120.0 + 24.0 + 4 * 24.0) * nl;   // W, S^-1 planes + b read; y, r, z, p written
+  } else if (h->grp_B > 1) {
+    dev::GroupPre GP;
+    GP.ginv = h->ginv;
+    GP.B = h->grp_B;
+    GP.nb = h->grp_nb;
+    GP.nb_pad = h->grp_pad;
+    GP.n_groups = h->n_groups;
+    PGOC(time_launches(h, reps, [&] {
+      hipLaunchKernelGGL(dev::k_cg_init_g, dim3(h->g_grp), dim3(dev::WG), 0, h->stream, V, GP, (const double*)h->gs, h->part[0], h->part[1]);
+    }, &ms));
+    out->algorithmic_bytes = (8.0 * 3 * h->grp_nb + 24.0 + 4 * 24.0) * nl;
+  } else {
+    PGOC(time_launches(h, reps, [&] {
+      hipLaunchKernelGGL(dev::k_cg_init, dim3(h->g_vec), dim3(dev::WG), 0, h->stream, V, (const double*)h->gs, h->part[0], h->part[1]);
+    }, &ms));
+    out->algorithmic_bytes = (48.0 + 24.0 + 4 * 24.0) * nl;
+  }
+  out->ms_avg = ms;
+  out->units = h->S.n_loc;
   return PGO_OK;
 }
 
