@@ -167,11 +167,12 @@ typedef struct pgo_options {
                                   (differentiated through s, as the reference differentiates through psi).  Needs the
                                   information matrices (pgo_create_weighted / pgo_create_from_graph), all positive
                                   definite; METHOD 2: PGO_ERR_UNSUPPORTED                                            */
-  int32_t pcg_chain_len;       /* chain preconditioner: block-Jacobi over segments of 64 consecutive poses whose blocks are
-                                  kept block-TRIDIAGONAL (the odometry chain inside the segment; every other edge only
-                                  adds its 3x3 diagonal blocks), factorised exactly per LM iteration and applied by two
-                                  wavefront scans.  64 = on (overrides pcg_block_poses), 0 = off,
-                                  -1 (default) = on when pcg_block_poses is 0 (auto) and the graph has > 8192 poses     */
+  int32_t pcg_chain_len;       /* chain preconditioner: block-Jacobi over segments of this many consecutive poses whose blocks
+                                  are kept block-TRIDIAGONAL (the odometry chain inside the segment; every other edge only
+                                  adds its 3x3 diagonal blocks), factorised exactly per LM iteration and applied by
+                                  chunked wavefront scans.  A multiple of 4 that divides 256 (64 = the measured default)
+                                  turns it on and overrides pcg_block_poses; 0 = off;
+                                  -1 (default) = 64 when pcg_block_poses is 0 (auto) and the graph has > 8192 poses       */
   int32_t reserved[1];
 } pgo_options;
 

@@ -282,17 +282,17 @@ def test_lm_inexact_matches_port_on_synthetic_10k(pgo, oracle):
     s.close()
 
 
-@pytest.mark.parametrize("n_poses,seed", [(10000, 20260410), (30011, 3)])
-def test_chain_preconditioner_matches_port(pgo, oracle, n_poses, seed):
-    """pcg_chain_len = 64: block-tridiagonal segments, factor (k_chain_factor) + wave-scan apply (k_cg_update1_c) against
-    the sequential block LDL' sweep of the C port: same LM history, PCG iteration counts within 1, and fewer PCG
-    iterations than the dense 4-pose blocks.  30011 poses: the last segment is short (ragged)."""
+@pytest.mark.parametrize("n_poses,seed,chain", [(10000, 20260410, 64), (30011, 3, 64), (30011, 3, 256), (9001, 4, 8)])
+def test_chain_preconditioner_matches_port(pgo, oracle, n_poses, seed, chain):
+    """pcg_chain_len: block-tridiagonal segments, factor (k_chain_factor) + chunked wave-scan apply (k_cg_update1_c)
+    against the sequential block LDL' sweep of the C port: same LM history, PCG iteration counts within 1, and fewer PCG
+    iterations than the dense 4-pose blocks.  30011 / 9001 poses: the last segment, chunk and 256-row tile are ragged."""
     g = pgo.synth_manhattan(n_poses, 4.0, 0.10, seed)
     og = oracle_graph(oracle, g)
     kw = dict(method=1, max_iters=6, pcg_rtol=0.1, pcg_max_iters=500)
-    s = pgo.Solver(g, pgo.Options(pcg_chain_len=64, **kw))
+    s = pgo.Solver(g, pgo.Options(pcg_chain_len=chain, **kw))
     summ = s.solve()
-    ores = oracle.lm_pcg(og, oracle.Options(threads=8, pcg_chain_len=64, **kw))
+    ores = oracle.lm_pcg(og, oracle.Options(threads=8, pcg_chain_len=chain, **kw))
     recs = s.iter_records()
     assert len(recs) == len(ores.records)
     for a, b in zip(recs, ores.records):
@@ -302,8 +302,11 @@ def test_chain_preconditioner_matches_port(pgo, oracle, n_poses, seed):
     assert np.abs(s.poses() - ores.poses).max() < 1e-7
     s4 = pgo.Solver(g, pgo.Options(pcg_block_poses=4, **kw))
     summ4 = s4.solve()
-    print(f"PCG iterations over 6 LM iterations, {n_poses} poses: chain-64 {summ.total_pcg_iters}, 4-pose blocks {summ4.total_pcg_iters}")
-    assert summ.total_pcg_iters < summ4.total_pcg_iters
+    print(f"PCG iterations over 6 LM iterations, {n_poses} poses: chain-{chain} {summ.total_pcg_iters}, 4-pose blocks {summ4.total_pcg_iters}")
+    if chain >= 64:
+        assert summ.total_pcg_iters < summ4.total_pcg_iters
+    with pytest.raises(pgo.PgoError):
+        pgo.Solver(g, pgo.Options(pcg_chain_len=48, **kw))     # must divide 256
     s.close(); s4.close()
 
 

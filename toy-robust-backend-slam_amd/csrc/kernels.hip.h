@@ -1067,30 +1067,46 @@ __global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int pa
 }
 
 // ------------------------------------------------- chain (block-tridiagonal) preconditioner
-// Block-Jacobi over segments of CHAIN = 64 consecutive poses (one wavefront) whose blocks are kept block-TRIDIAGONAL:
+// Block-Jacobi over segments of L consecutive poses (L = 64 by default; any multiple of 4 that divides 256) whose blocks
+// are kept block-TRIDIAGONAL:
 //     M_seg = sum of J'J over the edges joining consecutive poses of the segment (the odometry chain)
 //             + the 3x3 diagonal blocks of every other edge + D'D          (a sum of PSD terms + D'D: SPD)
 // i.e. the block-tridiagonal part of (H + D'D) inside the segment.  Factorised once per LM iteration as block LDL'
-//     S_i = M_ii - W_i C_i',   W_i = C_i S_{i-1}^-1,   C_i = H_{i,i-1}
+//     S_i = M_ii - W_i C_i',   W_i = C_i S_{i-1}^-1,   C_i = H_{i,i-1}      (W_i = 0 at a segment start)
 // (k_chain_factor, one thread per segment) and applied as  t_i = r_i - W_i t_{i-1};  z_i = S_i^-1 t_i - W_{i+1}' z_{i+1}.
-// Both recurrences are affine maps composed along the segment, so the apply is two wave-level scans (lane = pose,
-// 6 shuffle levels each) fused into the CG update kernels: 120 B/pose of factors per PCG iteration instead of the
-// 288 B/pose of the dense 4-pose blocks, and 20-60 % fewer PCG iterations on the 1M-pose graph.
-constexpr int CHAIN = 64;
+//
+// Apply (chain_apply, fused into the CG update kernels): one wavefront per tile of 256 rows, one lane per CHUNK of 4
+// consecutive poses.  Each recurrence is a composition of affine maps x -> a + F x, so a lane (1) sweeps its chunk from
+// a zero input, accumulating the chunk's map (a, F = product of its 4 matrices), (2) the 64 chunk maps are combined by
+// a Hillis-Steele scan over the wave (6 levels of (3-vector, 3x3) pairs), (3) the lane sweeps its chunk again from its
+// true input.  Because W = 0 at every segment start, the chunk maps of different segments do not interact: the scan needs
+// no segment masks and the kernel is independent of L.  Work per pose ~150 fp64 FMA and 4.5 64-bit shuffles (the
+// lane-per-pose scan this replaces: 380 FMA and 126 shuffles per pose, 76 us per apply at 1M poses, shuffle-bound).
+// Factor planes are stored TRANSPOSED inside each 256-row tile (chain_tidx) so that step k of all 64 lanes is one
+// coalesced 512-byte access; the vectors go through a wave-private LDS tile (coalesced global access, strided LDS access
+// with one pad per chunk: conflict-free).  120 B/pose of factors per PCG iteration (dense 4-pose blocks: 288 B/pose).
+constexpr int CHAIN_CHUNK = 4;
+constexpr int CHAIN_TILE = 256;                       // rows per wavefront = 64 lanes x CHAIN_CHUNK
+constexpr int CHAIN_LDS = CHAIN_TILE * 3 + 64;        // doubles of LDS per wavefront (one pad per chunk)
+
+__host__ __device__ __forceinline__ int64_t chain_tidx(int64_t i) {
+  return (i & ~(int64_t)(CHAIN_TILE - 1)) + ((i & (CHAIN_CHUNK - 1)) << 6) + ((i & (CHAIN_TILE - 1)) / CHAIN_CHUNK);
+}
 
 struct ChainPre {
-  const double* cw;   // 9 planes [n_loc]: W_i, row-major 3x3 (0 at a segment start)
-  const double* cs;   // 6 planes [n_loc]: S_i^-1 (00 01 02 11 12 22)
+  const double* cw;   // 9 planes [n_pad]: W_i, row-major 3x3, at chain_tidx(i); 0 at a segment start and in the padding
+  const double* cs;   // 6 planes [n_pad]: S_i^-1 (00 01 02 11 12 22), at chain_tidx(i); 0 in the padding
   int32_t n_loc;
+  int32_t n_pad;      // n_loc rounded up to whole 256-row tiles
 };
 
-// C_i: sum of the off-diagonal blocks (i, i-1) of row i (9 planes); 0 at a segment start
+// C_i: sum of the off-diagonal blocks (i, i-1) of row i (9 planes, natural order); 0 at a segment start
 __global__ void k_chain_extract(const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_col,
-                                const double* __restrict__ hoff, int n_loc, int lo, double* __restrict__ cc) {
+                                const double* __restrict__ hoff, int n_loc, int lo, int seg_len, double* __restrict__ cc) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_loc) return;
   double acc[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if ((row & (CHAIN - 1)) != 0) {
+  if ((row % seg_len) != 0) {
     const int target = lo + row - 1;
     for (int q = inc_ptr[row]; q < inc_ptr[row + 1]; ++q)
       if (inc_col[q] == target) {
@@ -1102,14 +1118,14 @@ __global__ void k_chain_extract(const int32_t* __restrict__ inc_ptr, const int32
   for (int c = 0; c < 9; ++c) cc[(int64_t)c * n_loc + row] = acc[c];
 }
 
-// one thread per segment, sequential along the chain (64 dependent 3x3 steps; once per LM iteration)
+// one thread per segment, sequential along the chain (seg_len dependent 3x3 steps; once per LM iteration)
 __global__ void k_chain_factor(const double* __restrict__ hd, const double* __restrict__ d2, const double* __restrict__ cc,
-                               int n_loc, double* __restrict__ cw, double* __restrict__ cs) {
+                               int n_loc, int n_pad, int seg_len, double* __restrict__ cw, double* __restrict__ cs) {
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n = n_loc;
-  const int64_t s0 = (int64_t)seg * CHAIN;
+  const int64_t n = n_loc, np = n_pad;
+  const int64_t s0 = (int64_t)seg * seg_len;
   if (s0 >= n) return;
-  const int64_t s1 = s0 + CHAIN < n ? s0 + CHAIN : n;
+  const int64_t s1 = s0 + seg_len < n ? s0 + seg_len : n;
   double p00 = 0.0, p01 = 0.0, p02 = 0.0, p11 = 0.0, p12 = 0.0, p22 = 0.0;  // S_{i-1}^-1
   for (int64_t i = s0; i < s1; ++i) {
     double a00 = hd[i] + d2[3 * i], a01 = hd[n + i], a02 = hd[2 * n + i], a11 = hd[3 * n + i] + d2[3 * i + 1],
@@ -1133,8 +1149,9 @@ __global__ void k_chain_factor(const double* __restrict__ hd, const double* __re
       a12 -= W[3] * C[6] + W[4] * C[7] + W[5] * C[8];
       a22 -= W[6] * C[6] + W[7] * C[7] + W[8] * C[8];
     }
+    const int64_t ti = chain_tidx(i);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) cw[(int64_t)c * n + i] = W[c];
+    for (int c = 0; c < 9; ++c) cw[(int64_t)c * np + ti] = W[c];
     const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
     const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
     p00 = c00 * id;
@@ -1143,12 +1160,12 @@ __global__ void k_chain_factor(const double* __restrict__ hd, const double* __re
     p11 = (a00 * a22 - a02 * a02) * id;
     p12 = (a01 * a02 - a00 * a12) * id;
     p22 = (a00 * a11 - a01 * a01) * id;
-    cs[i] = p00;
-    cs[n + i] = p01;
-    cs[2 * n + i] = p02;
-    cs[3 * n + i] = p11;
-    cs[4 * n + i] = p12;
-    cs[5 * n + i] = p22;
+    cs[ti] = p00;
+    cs[np + ti] = p01;
+    cs[2 * np + ti] = p02;
+    cs[3 * np + ti] = p11;
+    cs[4 * np + ti] = p12;
+    cs[5 * np + ti] = p22;
   }
 }
 
@@ -1168,90 +1185,191 @@ __device__ __forceinline__ void affine_compose(double a[3], double M[9], const d
   }
 }
 
-// z = M_seg^-1 r for the segment held by this wavefront (lane = pose).  Every lane of the wave must call it;
-// lanes with !valid pass zeros.  row = local row of this lane.
-// ABL != 0: timing-only ablations used by pgo_bench_precond (1: no backward scan, 2: no scans) -- wrong results.
-template <int ABL = 0>
-__device__ __forceinline__ void chain_apply(const ChainPre& C, int64_t row, bool valid, double r0, double r1, double r2,
-                                            double& z0, double& z1, double& z2) {
+// In place on the wave-private LDS tile `buf` (CHAIN_LDS doubles): on entry r of the 256 rows starting at `wbase`
+// (pose q, component c at q*3 + c + (q >> 2); rows >= n_loc hold 0), on exit z = M^-1 r.  All 64 lanes call it; the
+// caller separates it from its own accesses to `buf` with barriers.
+__device__ __forceinline__ void chain_apply(const ChainPre& C, int64_t wbase, double* __restrict__ buf) {
   const int lane = threadIdx.x & 63;
-  const int64_t n = C.n_loc;
-  double a[3] = {r0, r1, r2}, M[9];
-  const bool has_prev = valid && lane > 0;
+  const int64_t np = C.n_pad;
+  const double* cwl = C.cw + wbase + lane;  // + c * np + k * 64 : W of this lane's pose k, entry c
+  const double* csl = C.cs + wbase + lane;
+  double* ch = buf + lane * (3 * CHAIN_CHUNK + 1);  // this lane's chunk: pose k at 3 k
+  // The lane's factors are (re)loaded as one batch at the start of each sweep (coalesced; L2 hits after the first):
+  // one memory latency per sweep, and only one sweep's factors are live at a time.
+  double W[CHAIN_CHUNK][9];
+  auto load_w = [&](int shift) {  // shift 0: W_k of the chunk's poses; 1: W_{k+1} (the backward sweeps)
 #pragma unroll
-  for (int c = 0; c < 9; ++c) M[c] = has_prev ? -C.cw[(int64_t)c * n + row] : 0.0;
-  // forward: t_i = r_i - W_i t_{i-1}  (inclusive scan of affine maps, Hillis-Steele)
+    for (int k = 0; k < CHAIN_CHUNK; ++k) {
+      if (shift && k == CHAIN_CHUNK - 1) {
+        // the pose after the chunk = the next lane's first one (0 for lane 63: the next tile starts a segment)
 #pragma unroll
-  for (int off = 1; off < (ABL >= 2 ? 1 : 64); off <<= 1) {
+        for (int c = 0; c < 9; ++c) W[k][c] = lane < 63 ? cwl[(int64_t)c * np + 1] : 0.0;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) W[k][c] = cwl[(int64_t)c * np + (k + shift) * 64];
+      }
+    }
+  };
+  load_w(0);
+
+  double t[3] = {0.0, 0.0, 0.0}, F[9];
+  // ---- forward, pass 1: chunk map from a zero input:  t <- r_k - W_k t ;  F <- (-W_k) F
+#pragma unroll
+  for (int k = 0; k < CHAIN_CHUNK; ++k) {
+    const double* w = W[k];
+    const double t0 = ch[3 * k] - (w[0] * t[0] + w[1] * t[1] + w[2] * t[2]);
+    const double t1 = ch[3 * k + 1] - (w[3] * t[0] + w[4] * t[1] + w[5] * t[2]);
+    const double t2 = ch[3 * k + 2] - (w[6] * t[0] + w[7] * t[1] + w[8] * t[2]);
+    t[0] = t0; t[1] = t1; t[2] = t2;
+    if (k == 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) F[c] = -w[c];
+    } else {
+      double R[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = -(w[3 * i] * F[j] + w[3 * i + 1] * F[3 + j] + w[3 * i + 2] * F[6 + j]);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) F[c] = R[c];
+    }
+  }
+  // ---- scan of the chunk maps (inclusive): t becomes the true value at the end of this lane's chunk
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
     double b[3], N[9];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) b[k] = __shfl_up(a[k], off, 64);
+    for (int k = 0; k < 3; ++k) b[k] = __shfl_up(t[k], off, 64);
     if (off < 32) {
 #pragma unroll
-      for (int c = 0; c < 9; ++c) N[c] = __shfl_up(M[c], off, 64);
+      for (int c = 0; c < 9; ++c) N[c] = __shfl_up(F[c], off, 64);
     }
-    if (lane >= off) affine_compose(a, M, b, N, off < 32);
+    if (lane >= off) affine_compose(t, F, b, N, off < 32);
   }
-  // u = S^-1 t
-  double u[3] = {0.0, 0.0, 0.0};
-  if (valid) {
-    const double s00 = C.cs[row], s01 = C.cs[n + row], s02 = C.cs[2 * n + row], s11 = C.cs[3 * n + row],
-                 s12 = C.cs[4 * n + row], s22 = C.cs[5 * n + row];
-    u[0] = s00 * a[0] + s01 * a[1] + s02 * a[2];
-    u[1] = s01 * a[0] + s11 * a[1] + s12 * a[2];
-    u[2] = s02 * a[0] + s12 * a[1] + s22 * a[2];
+  // ---- forward, pass 2 from the true input (end of the previous chunk), then u = S^-1 t, stored over r
+  {
+    double S[CHAIN_CHUNK][6];
+#pragma unroll
+    for (int k = 0; k < CHAIN_CHUNK; ++k)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) S[k][c] = csl[(int64_t)c * np + k * 64];
+    double x0 = __shfl_up(t[0], 1, 64), x1 = __shfl_up(t[1], 1, 64), x2 = __shfl_up(t[2], 1, 64);
+    if (lane == 0) { x0 = 0.0; x1 = 0.0; x2 = 0.0; }
+#pragma unroll
+    for (int k = 0; k < CHAIN_CHUNK; ++k) {
+      const double* w = W[k];
+      const double* q = S[k];
+      const double t0 = ch[3 * k] - (w[0] * x0 + w[1] * x1 + w[2] * x2);
+      const double t1 = ch[3 * k + 1] - (w[3] * x0 + w[4] * x1 + w[5] * x2);
+      const double t2 = ch[3 * k + 2] - (w[6] * x0 + w[7] * x1 + w[8] * x2);
+      x0 = t0; x1 = t1; x2 = t2;
+      ch[3 * k] = q[0] * t0 + q[1] * t1 + q[2] * t2;
+      ch[3 * k + 1] = q[1] * t0 + q[3] * t1 + q[4] * t2;
+      ch[3 * k + 2] = q[2] * t0 + q[4] * t1 + q[5] * t2;
+    }
   }
-  // backward: z_i = u_i - W_{i+1}' z_{i+1}
-  const bool has_next = valid && lane < 63 && row + 1 < n;
+  // ---- backward, pass 1 (k = 3..0) from a zero input:  z <- u_k - W_{k+1}' z ;  F <- (-W_{k+1}') F
+  load_w(1);
+  t[0] = 0.0; t[1] = 0.0; t[2] = 0.0;
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int k = CHAIN_CHUNK - 1; k >= 0; --k) {
+    const double* w = W[k];
+    const double z0 = ch[3 * k] - (w[0] * t[0] + w[3] * t[1] + w[6] * t[2]);
+    const double z1 = ch[3 * k + 1] - (w[1] * t[0] + w[4] * t[1] + w[7] * t[2]);
+    const double z2 = ch[3 * k + 2] - (w[2] * t[0] + w[5] * t[1] + w[8] * t[2]);
+    t[0] = z0; t[1] = z1; t[2] = z2;
+    if (k == CHAIN_CHUNK - 1) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) M[3 * i + j] = has_next ? -C.cw[(int64_t)(3 * j + i) * n + row + 1] : 0.0;
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-  for (int off = 1; off < (ABL >= 1 ? 1 : 64); off <<= 1) {
+        for (int j = 0; j < 3; ++j) F[3 * i + j] = -w[3 * j + i];
+    } else {
+      double R[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = -(w[i] * F[j] + w[3 + i] * F[3 + j] + w[6 + i] * F[6 + j]);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) F[c] = R[c];
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
     double b[3], N[9];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) b[k] = __shfl_down(u[k], off, 64);
+    for (int k = 0; k < 3; ++k) b[k] = __shfl_down(t[k], off, 64);
     if (off < 32) {
 #pragma unroll
-      for (int c = 0; c < 9; ++c) N[c] = __shfl_down(M[c], off, 64);
+      for (int c = 0; c < 9; ++c) N[c] = __shfl_down(F[c], off, 64);
     }
-    if (lane + off < 64) affine_compose(u, M, b, N, off < 32);
+    if (lane + off < 64) affine_compose(t, F, b, N, off < 32);
   }
-  z0 = u[0];
-  z1 = u[1];
-  z2 = u[2];
+  // ---- backward, pass 2 from the true input (start of the next chunk), z stored over u
+  {
+    double x0 = __shfl_down(t[0], 1, 64), x1 = __shfl_down(t[1], 1, 64), x2 = __shfl_down(t[2], 1, 64);
+    if (lane == 63) { x0 = 0.0; x1 = 0.0; x2 = 0.0; }
+#pragma unroll
+    for (int k = CHAIN_CHUNK - 1; k >= 0; --k) {
+      const double* w = W[k];
+      const double z0 = ch[3 * k] - (w[0] * x0 + w[3] * x1 + w[6] * x2);
+      const double z1 = ch[3 * k + 1] - (w[1] * x0 + w[4] * x1 + w[7] * x2);
+      const double z2 = ch[3 * k + 2] - (w[2] * x0 + w[5] * x1 + w[8] * x2);
+      x0 = z0; x1 = z1; x2 = z2;
+      ch[3 * k] = z0;
+      ch[3 * k + 1] = z1;
+      ch[3 * k + 2] = z2;
+    }
+  }
 }
 
-template <int ABL>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cg_init_c(CgVec V, ChainPre C, const double* __restrict__ b,
+// LDS position of flat element e (= 3 * pose + component) of a wave tile
+__device__ __forceinline__ int chain_lds_pos(int e) { return e + e / (3 * CHAIN_CHUNK); }
+
+// PCG start-up with the chain preconditioner: r = b, z = M^-1 r, y = 0, p = z; partials of r.z and b.b.
+// One wavefront per 256-row tile; workgroup = 4 waves = 1024 rows.
+__global__ __launch_bounds__(WG) void k_cg_init_c(CgVec V, ChainPre C, const double* __restrict__ b,
                                                   double* __restrict__ part_rz, double* __restrict__ part_bb) {
+  __shared__ double tile[4][CHAIN_LDS];
   __shared__ double red[8];
-  const int tid = threadIdx.x;
-  const int64_t n = V.n_loc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* buf = tile[wave];
+  const int64_t n3 = 3 * (int64_t)V.n_loc;
+  // distinct arrays: let the compiler batch the loads of an unrolled group ahead of its stores
+  double* __restrict__ vy = V.y;
+  double* __restrict__ vr = V.r;
+  double* __restrict__ vz = V.z;
+  double* __restrict__ vp = V.p + 3 * (int64_t)V.lo;
   double rz = 0.0, bb = 0.0;
-  for (int64_t base = (int64_t)blockIdx.x * WG; base < n; base += (int64_t)gridDim.x * WG) {
-    const int64_t row = base + tid;
-    const bool valid = row < n;
-    double r0 = 0.0, r1 = 0.0, r2 = 0.0, z0, z1, z2;
-    if (valid) {
-      r0 = b[3 * row];
-      r1 = b[3 * row + 1];
-      r2 = b[3 * row + 2];
+  for (int64_t wg_base = (int64_t)blockIdx.x * (4 * CHAIN_TILE); wg_base < V.n_loc; wg_base += (int64_t)gridDim.x * (4 * CHAIN_TILE)) {
+    const int64_t wbase = wg_base + (int64_t)wave * CHAIN_TILE;
+    const bool active = wbase < V.n_loc;
+    const int64_t f0 = 3 * wbase;
+    if (active) {
+#pragma unroll 4
+      for (int e = lane; e < 3 * CHAIN_TILE; e += 64) {
+        const int64_t idx = f0 + e;
+        buf[chain_lds_pos(e)] = idx < n3 ? b[idx] : 0.0;
+      }
     }
-    chain_apply<ABL>(C, row, valid, r0, r1, r2, z0, z1, z2);
-    if (valid) {
-      double* y = V.y + 3 * row;
-      double* r = V.r + 3 * row;
-      double* z = V.z + 3 * row;
-      double* p = V.p + 3 * ((int64_t)V.lo + row);
-      y[0] = 0.0; y[1] = 0.0; y[2] = 0.0;
-      r[0] = r0; r[1] = r1; r[2] = r2;
-      z[0] = z0; z[1] = z1; z[2] = z2;
-      p[0] = z0; p[1] = z1; p[2] = z2;
-      rz += r0 * z0 + r1 * z1 + r2 * z2;
-      bb += r0 * r0 + r1 * r1 + r2 * r2;
+    __syncthreads();
+    if (active) chain_apply(C, wbase, buf);
+    __syncthreads();
+    if (active) {
+#pragma unroll 4
+      for (int e = lane; e < 3 * CHAIN_TILE; e += 64) {
+        const int64_t idx = f0 + e;
+        if (idx < n3) {
+          const double z = buf[chain_lds_pos(e)], r = b[idx];
+          vy[idx] = 0.0;
+          vr[idx] = r;
+          vz[idx] = z;
+          vp[idx] = z;
+          rz += r * z;
+          bb += r * r;
+        }
+      }
     }
+    __syncthreads();
   }
   rz = block_sum_bcast(rz, red);
   bb = block_sum_bcast(bb, red);
@@ -1261,39 +1379,56 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
 }
 
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cg_update1_c(CgVec V, ChainPre C, int parity, const double* __restrict__ part_pap,
+// x += alpha p ; r -= alpha A p ; z = M^-1 r (chain) ; partials of r.z and r.r
+__global__ __launch_bounds__(WG) void k_cg_update1_c(CgVec V, ChainPre C, int parity, const double* __restrict__ part_pap,
                                                      int n_pap, double* __restrict__ part_rz, double* __restrict__ part_rr) {
+  __shared__ double tile[4][CHAIN_LDS];
   __shared__ double red[8];
   if (V.st->done) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double pap = sum_partials_bcast(part_pap, n_pap, red);
   const double alpha = V.st->rz[parity] / pap;
-  const int64_t n = V.n_loc;
+  double* buf = tile[wave];
+  const int64_t n3 = 3 * (int64_t)V.n_loc;
+  double* __restrict__ vy = V.y;
+  double* __restrict__ vr = V.r;
+  double* __restrict__ vz = V.z;
+  const double* __restrict__ vap = V.ap;
+  const double* __restrict__ pown = V.p + 3 * (int64_t)V.lo;
   double rz = 0.0, rr = 0.0;
-  for (int64_t base = (int64_t)blockIdx.x * WG; base < n; base += (int64_t)gridDim.x * WG) {
-    const int64_t row = base + tid;
-    const bool valid = row < n;
-    double r0 = 0.0, r1 = 0.0, r2 = 0.0, z0, z1, z2;
-    if (valid) {
-      double* y = V.y + 3 * row;
-      double* r = V.r + 3 * row;
-      const double* p = V.p + 3 * ((int64_t)V.lo + row);
-      const double* ap = V.ap + 3 * row;
-      y[0] += alpha * p[0];
-      y[1] += alpha * p[1];
-      y[2] += alpha * p[2];
-      r0 = r[0] - alpha * ap[0];
-      r1 = r[1] - alpha * ap[1];
-      r2 = r[2] - alpha * ap[2];
-      r[0] = r0; r[1] = r1; r[2] = r2;
+  for (int64_t wg_base = (int64_t)blockIdx.x * (4 * CHAIN_TILE); wg_base < V.n_loc; wg_base += (int64_t)gridDim.x * (4 * CHAIN_TILE)) {
+    const int64_t wbase = wg_base + (int64_t)wave * CHAIN_TILE;
+    const bool active = wbase < V.n_loc;
+    const int64_t f0 = 3 * wbase;
+    if (active) {
+#pragma unroll 4
+      for (int e = lane; e < 3 * CHAIN_TILE; e += 64) {
+        const int64_t idx = f0 + e;
+        double r = 0.0;
+        if (idx < n3) {
+          vy[idx] += alpha * pown[idx];
+          r = vr[idx] - alpha * vap[idx];
+          vr[idx] = r;
+        }
+        buf[chain_lds_pos(e)] = r;
+      }
     }
-    chain_apply(C, row, valid, r0, r1, r2, z0, z1, z2);
-    if (valid) {
-      double* z = V.z + 3 * row;
-      z[0] = z0; z[1] = z1; z[2] = z2;
-      rz += r0 * z0 + r1 * z1 + r2 * z2;
-      rr += r0 * r0 + r1 * r1 + r2 * r2;
+    __syncthreads();
+    if (active) chain_apply(C, wbase, buf);
+    __syncthreads();
+    if (active) {
+#pragma unroll 4
+      for (int e = lane; e < 3 * CHAIN_TILE; e += 64) {
+        const int64_t idx = f0 + e;
+        if (idx < n3) {
+          const double z = buf[chain_lds_pos(e)], r = vr[idx];
+          vz[idx] = z;
+          rz += r * z;
+          rr += r * r;
+        }
+      }
     }
+    __syncthreads();
   }
   rz = block_sum_bcast(rz, red);
   rr = block_sum_bcast(rr, red);

@@ -96,7 +96,7 @@ struct pgo_handle {
   int grp_prep_grid = 1;
   double* ginv = nullptr;
   // chain (block-tridiagonal) preconditioner over 64-pose segments (opt.pcg_chain_len): C planes, W planes, S^-1 planes
-  int chain_len = 0, g_chain = 1;
+  int chain_len = 0, g_chain = 1, chain_pad = 0;
   double *chain_c = nullptr, *chain_w = nullptr, *chain_s = nullptr;
   // halo exchange of the search direction (world > 1, opt.halo_exchange)
   bool use_halo = false;
@@ -394,8 +394,8 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   force_collectives = fc && fc[0] == '1';
   grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
   chain_len = pgo::resolve_chain_len(opt.pcg_chain_len, opt.pcg_block_poses, N);
-  if (chain_len != 0 && chain_len != dev::CHAIN)
-    return fail(PGO_ERR_INVALID_ARG, "pcg_chain_len: the device kernels use segments of 64 poses (one wavefront): pass 64, 0 or -1");
+  if (chain_len != 0 && (chain_len < dev::CHAIN_CHUNK || chain_len % dev::CHAIN_CHUNK != 0 || dev::CHAIN_TILE % chain_len != 0))
+    return fail(PGO_ERR_INVALID_ARG, "pcg_chain_len: a multiple of 4 that divides 256 (4 ... 256), 0 = off, -1 = auto");
   if (chain_len) grp_B = 1;
   // internal pose numbering
   const bool reorder = opt.pose_ordering == 1 || (opt.pose_ordering < 0 && world > 1);
@@ -403,7 +403,8 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   std::vector<double> poses_p;
   fixed_internal = opt.fixed_pose;
   if (reorder) {
-    PGOC(pgo::compute_pose_order(N, E, ia, ib, pgo::ORDER_SEGMENT, &perm));
+    // chain segments must stay contiguous under the renumbering
+    PGOC(pgo::compute_pose_order(N, E, ia, ib, std::max<int>(pgo::ORDER_SEGMENT, chain_len), &perm));
     ia_p.resize(E);
     ib_p.resize(E);
     for (int32_t e = 0; e < E; ++e) {
@@ -534,10 +535,14 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     grp_B = 1;
   }
   if (chain_len && NL > 0) {
+    chain_pad = (int)(((NL + dev::CHAIN_TILE - 1) / dev::CHAIN_TILE) * dev::CHAIN_TILE);
     PGOC(dalloc(&chain_c, 9 * NL));
-    PGOC(dalloc(&chain_w, 9 * NL));
-    PGOC(dalloc(&chain_s, 6 * NL));
-    g_chain = (int)std::min<int64_t>((NL + dev::WG - 1) / dev::WG, 2048);
+    PGOC(dalloc(&chain_w, 9 * (int64_t)chain_pad));
+    PGOC(dalloc(&chain_s, 6 * (int64_t)chain_pad));
+    // the padding rows of the factor planes are never written: they must read as 0
+    HIPC(hipMemsetAsync(chain_w, 0, (size_t)9 * chain_pad * sizeof(double), stream));
+    HIPC(hipMemsetAsync(chain_s, 0, (size_t)6 * chain_pad * sizeof(double), stream));
+    g_chain = (int)std::min<int64_t>((NL + 4 * dev::CHAIN_TILE - 1) / (4 * dev::CHAIN_TILE), 2048);
   } else {
     chain_len = 0;
   }
@@ -672,8 +677,9 @@ int pgo_handle::pcg(int* iters, double* rel) {
   CP.cw = chain_w;
   CP.cs = chain_s;
   CP.n_loc = S.n_loc;
+  CP.n_pad = chain_pad;
   const int g_u1 = chained ? g_chain : (grouped ? g_grp : g_vec);  // grid (= number of partials) of the init / update1 kernels
-  if (chained) hipLaunchKernelGGL(dev::k_cg_init_c<0>, dim3(g_u1), dim3(dev::WG), 0, stream, V, CP, (const double*)gs, part[0], part[1]);
+  if (chained) hipLaunchKernelGGL(dev::k_cg_init_c, dim3(g_u1), dim3(dev::WG), 0, stream, V, CP, (const double*)gs, part[0], part[1]);
   else if (grouped) hipLaunchKernelGGL(dev::k_cg_init_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, (const double*)gs, part[0], part[1]);
   else hipLaunchKernelGGL(dev::k_cg_init, dim3(g_u1), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
   PGOC(check_launch("k_cg_init"));
@@ -793,11 +799,11 @@ int pgo_handle::lm_iteration(bool* stop) {
   }
   if (chain_len) {
     hipLaunchKernelGGL(dev::k_chain_extract, dim3(g_rows), dim3(dev::WG), 0, stream, (const int32_t*)inc_ptr, (const int32_t*)inc_col,
-                       (const double*)hoff, S.n_loc, S.lo, chain_c);
+                       (const double*)hoff, S.n_loc, S.lo, chain_len, chain_c);
     PGOC(check_launch("k_chain_extract"));
-    const int n_seg = (S.n_loc + dev::CHAIN - 1) / dev::CHAIN;
+    const int n_seg = (S.n_loc + chain_len - 1) / chain_len;
     hipLaunchKernelGGL(dev::k_chain_factor, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)hd, (const double*)d2,
-                       (const double*)chain_c, S.n_loc, chain_w, chain_s);
+                       (const double*)chain_c, S.n_loc, chain_pad, chain_len, chain_w, chain_s);
     PGOC(check_launch("k_chain_factor"));
   }
   int k_it = 0;
@@ -1336,8 +1342,6 @@ int pgo_bench_precond(pgo_t* h, int reps, pgo_kernel_stats* out) {
   if (!h->lin_valid || h->iter < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_precond: run at least one LM iteration first");
   HIPC(hipSetDevice(h->device));
   dev::CgVec V = h->cg_vec();
-  const char* ab = getenv("PGO_CHAIN_ABLATE");
-  const int abl = ab ? atoi(ab) : 0;
   double ms = 0;
   const double nl = (double)h->S.n_loc;
   if (h->chain_len) {
@@ -1345,10 +1349,9 @@ int pgo_bench_precond(pgo_t* h, int reps, pgo_kernel_stats* out) {
     CP.cw = h->chain_w;
     CP.cs = h->chain_s;
     CP.n_loc = h->S.n_loc;
+    CP.n_pad = h->chain_pad;
     PGOC(time_launches(h, reps, [&] {
-      if (abl == 1) hipLaunchKernelGGL(dev::k_cg_init_c<1>, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->gs, h->part[0], h->part[1]);
-      else if (abl == 2) hipLaunchKernelGGL(dev::k_cg_init_c<2>, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->gs, h->part[0], h->part[1]);
-      else hipLaunchKernelGGL(dev::k_cg_init_c<0>, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->gs, h->part[0], h->part[1]);
+      hipLaunchKernelGGL(dev::k_cg_init_c, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->gs, h->part[0], h->part[1]);
     }, &ms));
     out->algorithmic_bytes = (120.0 + 24.0 + 4 * 24.0) * nl;   // W, S^-1 planes + b read; y, r, z, p written
   } else if (h->grp_B > 1) {
