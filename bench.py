@@ -100,7 +100,7 @@ def main():
                     halo_exchange=args.halo_exchange,
                     pcg_check_every=min(100, max(1, args.pcg_max_iters)), verbose=args.verbose if rank == 0 else 0)
     # the preconditioner the library resolves for these options (pgo_internal.h resolve_chain_len / resolve_block_poses)
-    chain = args.pcg_chain_len if args.pcg_chain_len >= 0 else (64 if (args.pcg_block_poses <= 0 and g.n_poses > 8192) else 0)
+    chain = args.pcg_chain_len if args.pcg_chain_len >= 0 else (64 if (args.pcg_block_poses <= 0 and g.n_poses > 50000) else 0)
     blockp = args.pcg_block_poses if args.pcg_block_poses > 0 else (32 if g.n_poses <= 8192 else 4)
     precond = ("block-tridiagonal 64-pose chain segments" if chain else "dense %d-pose blocks" % blockp)
     t_create = time.time()

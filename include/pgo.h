@@ -172,7 +172,7 @@ typedef struct pgo_options {
                                   adds its 3x3 diagonal blocks), factorised exactly per LM iteration and applied by
                                   chunked wavefront scans.  A multiple of 4 that divides 256 (64 = the measured default)
                                   turns it on and overrides pcg_block_poses; 0 = off;
-                                  -1 (default) = 64 when pcg_block_poses is 0 (auto) and the graph has > 8192 poses       */
+                                  -1 (default) = 64 when pcg_block_poses is 0 (auto) and the graph has > 50000 poses       */
   int32_t reserved[1];
 } pgo_options;
 

@@ -49,7 +49,9 @@ def main():
     for n in (10000, 100000, 1000000):
         g = P.synth_manhattan(n, 4.0, 0.10, 20260410)
         iters = 10
-        kw = dict(method=1, max_iters=iters, ftol=0.0, gtol=0.0, ptol=0.0, pcg_rtol=0.1, pcg_max_iters=500, pcg_chain_len=64)
+        chain = n > 50000   # the library's auto rule (pgo_internal.h resolve_chain_len)
+        kw = dict(method=1, max_iters=iters, ftol=0.0, gtol=0.0, ptol=0.0, pcg_rtol=0.1, pcg_max_iters=500,
+                  pcg_chain_len=64 if chain else 0, pcg_block_poses=0 if chain else 4)
         s = P.Solver(g, P.Options(pcg_check_every=100, **kw))
         s.solve()
         s.set_poses(np.array(g.poses))
@@ -64,7 +66,7 @@ def main():
         ores = O.lm_pcg(og(g), O.Options(threads=threads, **dict(kw, max_iters=cpu_iters)))
         odt = time.perf_counter() - t
         rows.append(dict(workload="synthetic Manhattan %d poses, 10%% outliers, DCS" % n, poses=g.n_poses, edges=g.n_edges,
-                         policy="inexact (eta 0.1, <= 500 PCG, 64-pose chain segments)", lm_iters=summ.iterations, pcg_iters=summ.total_pcg_iters,
+                         policy="inexact (eta 0.1, <= 500 PCG, %s)" % ("64-pose chain segments" if chain else "4-pose blocks"), lm_iters=summ.iterations, pcg_iters=summ.total_pcg_iters,
                          gpu_s=dt, gpu_it_s=summ.iterations / dt, cpu_kind="oracle lm_pcg (C port, %d threads)" % threads,
                          cpu_s=odt, cpu_it_s=ores.iterations / odt, final_cost_gpu=summ.final_cost,
                          final_cost_cpu=ores.final_cost, edges_per_s_k1=k1.units / (k1.ms_avg * 1e-3),

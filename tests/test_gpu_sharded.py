@@ -59,18 +59,20 @@ def test_sharded_tight_solve_intel(tmp_path, world):
     assert np.abs(poses[0] - ref_poses[0]).max() < 1e-7
 
 
-@pytest.mark.parametrize("world,halo", [(2, 0), (4, 0), (2, 1), (3, 1), (4, 1)])
-def test_sharded_inexact_solve_synthetic(tmp_path, world, halo):
-    """halo = 0: all-gather of the search direction; halo = 1: point-to-point exchange of the referenced rows"""
-    cfg = dict(graph="synth", n_poses=20001, seed=9, options=dict(method=1, max_iters=4, pcg_rtol=0.1, pcg_max_iters=300))
-    ref, ref_poses = run(1, cfg, tmp_path)
+@pytest.mark.parametrize("world,halo,chain", [(2, 0, 0), (4, 0, 0), (2, 1, 0), (3, 1, 0), (4, 1, 0), (2, 1, 64), (3, 0, 64), (4, 1, 64)])
+def test_sharded_inexact_solve_synthetic(tmp_path, world, halo, chain):
+    """halo = 0: all-gather of the search direction; halo = 1: point-to-point exchange of the referenced rows;
+    chain = 64: the chain preconditioner (shards aligned to its segments) instead of the dense 4-pose blocks"""
+    cfg = dict(graph="synth", n_poses=20001, seed=9,
+               options=dict(method=1, max_iters=4, pcg_rtol=0.1, pcg_max_iters=300, pcg_chain_len=chain))
+    ref, ref_poses = run(1, cfg, tmp_path, tag="c%d" % chain)
     cfg = dict(cfg, options=dict(cfg["options"], halo_exchange=halo))
-    res, poses = run(world, cfg, tmp_path, tag="h%d" % halo)
+    res, poses = run(world, cfg, tmp_path, tag="h%dc%d" % (halo, chain))
     for r in range(world):
         np.testing.assert_array_equal(poses[r], poses[0])
         for a, b in zip(res[r]["records"], ref[0]["records"]):
             assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-8)
-            assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 1  # shard boundaries are aligned to the 4-pose blocks
+            assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 1  # shard boundaries are aligned to the preconditioner blocks
     assert np.abs(poses[0] - ref_poses[0]).max() < 1e-6
 
 
