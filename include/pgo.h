@@ -266,6 +266,12 @@ int pgo_edge_chi2(pgo_t* h, const double* poses_or_null, double* chi2_out /* E *
 
 /* ceres::Solve (main.cpp:163): LM from the current poses for opt.max_iters.      */
 int pgo_solve(pgo_t* h, pgo_summary* s);                                          /* [gpu] */
+/* Many independent problems at once (the reference's layer managers run ceres::Solve per candidate layer / window,
+ * src/simple_layer_manager.cpp:457-622, src/layer_manager.cpp:104-179): pgo_solve on each of the n handles, driven by
+ * up to max_concurrency host threads (<= 0: 8).  Every handle has its own HIP stream, so the launch-bound small solves
+ * overlap on the device; each handle's result is bitwise what pgo_solve alone gives.  summaries: n entries or NULL.
+ * Handles with a communicator are refused (PGO_ERR_UNSUPPORTED).  Returns the first failing status.                */
+int pgo_solve_batch(pgo_t* const* handles, int32_t n, pgo_summary* summaries, int32_t max_concurrency);   /* [gpu] */
 /* the same minimiser, resumable: (re)start with pgo_lm_begin, then run LM
  * iterations in slices (bench.py times slices); returns *done != 0 once a
  * termination test fired.                                                        */

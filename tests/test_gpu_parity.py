@@ -697,3 +697,90 @@ def test_info_weighting_errors(pgo):
     out = np.zeros(g.n_edges)
     assert pgo.lib().pgo_edge_chi2(h, None, dp(out)) < 0      # no information matrices in this handle
     pgo.lib().pgo_destroy(h)
+
+
+# ------------------------------------------ batched independent solves (pgo_solve_batch)
+def _layer_problems(pgo, n_layers, seed=0):
+    """problems shaped like the reference's layer managers build them (src/simple_layer_manager.cpp:457-497, 462-564;
+    src/layer_manager.cpp:104-178): a full-graph copy with the odometry edges + the layer's own subset of loop / bogus
+    edges, and windows [min(a,b) - R, max(a,b) + R] around one loop edge with the first window pose as the anchor; every
+    edge uses the plain functor (METHOD 0) with Huber, 2 LM iterations (local_iters)"""
+    import numpy as np
+    g = load(pgo, "INTEL", 50)
+    poses, ia, ib, meas, kind = (np.array(x) for x in (g.poses, g.ia, g.ib, g.meas, g.kind))
+    rng = np.random.default_rng(seed)
+    loops = np.nonzero(kind != 0)[0]
+    out = []
+    for l in range(n_layers):
+        keep = np.ones(len(ia), bool)
+        keep[loops] = rng.random(len(loops)) < 0.5          # this layer's edge set
+        if l % 2 == 0:
+            sel = keep
+            lo = 0
+            n = len(poses)
+        else:                                               # commit window around one of its loop edges, radius 30
+            e = loops[keep[loops]][l % max(1, keep[loops].sum())]
+            lo, hi = max(0, min(ia[e], ib[e]) - 30), min(len(poses) - 1, max(ia[e], ib[e]) + 30)
+            sel = keep & (ia >= lo) & (ia <= hi) & (ib >= lo) & (ib <= hi)
+            n = hi - lo + 1
+        out.append(pgo.Graph.from_arrays(poses[lo:lo + n], ia[sel] - lo, ib[sel] - lo, meas[sel], kind[sel]))
+    return out
+
+
+def test_solve_batch_equals_individual_solves(pgo):
+    import time
+    graphs = _layer_problems(pgo, 12)
+    opt = dict(method=0, max_iters=2, fixed_pose=0)
+    single = [pgo.Solver(g, pgo.Options(**opt)) for g in graphs]
+    t = time.perf_counter()
+    s_single = [s.solve() for s in single]
+    t_single = time.perf_counter() - t
+    batch = [pgo.Solver(g, pgo.Options(**opt)) for g in graphs]
+    pgo.solve_batch(batch[:1], 1)                            # warm-up of the code path
+    batch[0].set_poses(np.array(graphs[0].poses))
+    t = time.perf_counter()
+    s_batch = pgo.solve_batch(batch, 6)
+    t_batch = time.perf_counter() - t
+    print(f"12 layer problems (6 full INTEL copies, 6 windows), 2 LM iterations each: one by one {t_single*1e3:.1f} ms, "
+          f"pgo_solve_batch(6 threads) {t_batch*1e3:.1f} ms")
+    for a, b, sa, sb in zip(single, batch, s_single, s_batch):
+        assert sa.iterations == sb.iterations and sa.final_cost == sb.final_cost and sa.total_pcg_iters == sb.total_pcg_iters
+        np.testing.assert_array_equal(a.poses(), b.poses())  # bitwise: a handle's result does not depend on its neighbours
+    for s in single + batch:
+        s.close()
+
+
+def test_solve_batch_errors_and_empty(pgo):
+    import ctypes as C
+    assert pgo.solve_batch([]) == []
+    g = load(pgo, "INTEL")
+    s = pgo.Solver(g, pgo.Options(method=0, max_iters=1))
+    hs = (C.c_void_p * 2)(s._h, s._h)
+    assert pgo.lib().pgo_solve_batch(hs, 2, None, 2) < 0     # the same handle twice
+    hs = (C.c_void_p * 2)(s._h, None)
+    assert pgo.lib().pgo_solve_batch(hs, 2, None, 2) < 0     # null handle
+    # a failing problem reports its index: non-finite pose -> evaluation failure
+    bad = np.array(g.poses)
+    bad[5, 0] = np.nan
+    s.set_poses(bad)
+    ok = pgo.Solver(g, pgo.Options(method=0, max_iters=1))
+    with pytest.raises(pgo.PgoError) as ei:
+        pgo.solve_batch([ok, s], 2)
+    assert "problem 1" in str(ei.value)
+    s.close(); ok.close()
+
+
+def test_host_solve_batch(tmp_path):
+    """pgo::SolveBatch in the C++ mirror of the reference interface (tests/native/solve_batch_main.cpp): six layer
+    problems built the way src/simple_layer_manager.cpp:457-497 builds them, solved as one batch and one by one"""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "solve_batch_main")
+    pkg = os.path.join(ROOT, "toy-robust-backend-slam_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "host"),
+                           os.path.join(ROOT, "tests", "native", "solve_batch_main.cpp"), "-o", exe, "-L" + pkg, "-lpgo",
+                           "-Wl,-rpath," + pkg])
+    p = subprocess.run([exe, os.path.join(DATA, "INTEL.g2o")], capture_output=True, text=True, timeout=300)
+    print(p.stdout)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "solve batch ok" in p.stdout and p.stdout.count("layer ") == 6

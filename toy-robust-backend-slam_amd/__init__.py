@@ -21,7 +21,7 @@ import numpy as np
 from . import _build
 
 __all__ = ["PgoError", "Options", "Summary", "IterRecord", "ReadG2O", "Graph", "Solver", "Comm", "lib", "build",
-           "synth_manhattan", "shard_plan", "shard_halo", "pose_order", "KernelStats", "EXPORTS", "TERMINATION"]
+           "synth_manhattan", "solve_batch", "shard_plan", "shard_halo", "pose_order", "KernelStats", "EXPORTS", "TERMINATION"]
 
 EDGE_ODOMETRY, EDGE_CLOSURE, EDGE_BOGUS = 0, 1, 2
 TERMINATION = {1: "CONVERGENCE_FTOL", 2: "CONVERGENCE_GTOL", 3: "CONVERGENCE_PTOL", 4: "NO_CONVERGENCE",
@@ -36,7 +36,7 @@ EXPORTS = [
     "pgo_graph_edge_kind", "pgo_inject_outliers", "pgo_write_nodes", "pgo_write_edges", "pgo_write_g2o",
     "pgo_synth_manhattan", "pgo_options_default",
     "pgo_comm_unique_id", "pgo_comm_create_rccl", "pgo_comm_create_shm", "pgo_comm_destroy",
-    "pgo_create", "pgo_create_weighted", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_edge_chi2", "pgo_solve", "pgo_lm_begin", "pgo_lm_step",
+    "pgo_create", "pgo_create_weighted", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_edge_chi2", "pgo_solve", "pgo_solve_batch", "pgo_lm_begin", "pgo_lm_step",
     "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
     "pgo_write_switches",
     "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_bench_precond", "pgo_debug_spmv", "pgo_debug_normal_eq",
@@ -153,6 +153,7 @@ def lib():
     L.pgo_create_weighted.argtypes = [C.POINTER(vp), C.c_int32, dp, C.c_int32, ip, ip, dp, dp, bp, C.POINTER(Options), vp, C.c_int]
     L.pgo_create_from_graph.argtypes = [C.POINTER(vp), vp, C.POINTER(Options), vp, C.c_int]
     L.pgo_edge_chi2.argtypes = [vp, dp, dp]
+    L.pgo_solve_batch.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(Summary), C.c_int32]
     L.pgo_destroy.argtypes = [vp]
     L.pgo_destroy.restype = None
     L.pgo_eval.argtypes = [vp, dp, C.c_int, dp, dp, dp]
@@ -382,6 +383,15 @@ class Comm:
         if self._h:
             lib().pgo_comm_destroy(self._h)
             self._h = None
+
+
+def solve_batch(solvers, max_concurrency: int = 8):
+    """pgo_solve_batch: solve every Solver in the list (independent problems) concurrently; returns their summaries"""
+    n = len(solvers)
+    hs = (C.c_void_p * max(n, 1))(*[s._h for s in solvers])
+    out = (Summary * max(n, 1))()
+    _check(lib().pgo_solve_batch(hs, n, out, max_concurrency))
+    return [out[i] for i in range(n)]
 
 
 class Solver:

@@ -35,7 +35,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB + ".tmp", "-lrccl"]
+    cmd += ["-o", LIB + ".tmp", "-lrccl", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -11,7 +11,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <functional>
 #include <cmath>
 #include <cstdio>
@@ -1204,6 +1207,47 @@ int pgo_solve(pgo_t* h, pgo_summary* s) {
   while (!stop) PGOC(h->lm_iteration(&stop));
   h->lm_done = true;
   h->fill_summary(s);
+  return PGO_OK;
+}
+
+// Many independent solves at once (the reference's layer managers call ceres::Solve on a full-graph copy
+// or a window per candidate layer / edge, src/simple_layer_manager.cpp:457-622, src/layer_manager.cpp:104-179): every
+// handle owns its stream, device buffers and captured hipGraph, so `max_concurrency` host threads drive that many LM
+// solves concurrently and the launch-/latency-bound small problems overlap on the device.
+int pgo_solve_batch(pgo_t* const* handles, int32_t n, pgo_summary* summaries, int32_t max_concurrency) {
+  if (n < 0 || (n > 0 && !handles)) return fail(PGO_ERR_INVALID_ARG, "pgo_solve_batch: bad argument");
+  for (int32_t i = 0; i < n; ++i) {
+    if (!handles[i]) return fail(PGO_ERR_INVALID_ARG, "pgo_solve_batch: null handle " + std::to_string(i));
+    if (handles[i]->comm) return fail(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: handles with a communicator solve collectively, one at a time");
+    for (int32_t j = 0; j < i; ++j)
+      if (handles[j] == handles[i]) return fail(PGO_ERR_INVALID_ARG, "pgo_solve_batch: handle " + std::to_string(i) + " listed twice");
+  }
+  if (n == 0) return PGO_OK;
+  const int n_thr = std::max(1, std::min<int>(n, max_concurrency > 0 ? max_concurrency : 8));
+  std::atomic<int32_t> next(0);
+  std::mutex mu;
+  int first_status = PGO_OK;
+  std::string first_msg;
+  auto worker = [&] {
+    for (;;) {
+      const int32_t i = next.fetch_add(1);
+      if (i >= n) return;
+      pgo_summary tmp;
+      const int st = pgo_solve(handles[i], summaries ? &summaries[i] : &tmp);
+      if (st != PGO_OK) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (first_status == PGO_OK) {
+          first_status = st;
+          first_msg = "problem " + std::to_string(i) + ": " + pgo_last_error();  // the worker's thread-local text
+        }
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_thr; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+  if (first_status != PGO_OK) return fail(first_status, first_msg);
   return PGO_OK;
 }
 

@@ -132,7 +132,11 @@ struct Summary {
 }  // namespace Solver
 
 struct SolverAccess {
-  static void Solve(const Solver::Options& opt, Problem* pr, Solver::Summary* sum) {
+  static void check(int st) {
+    if (st != PGO_OK) throw std::runtime_error(std::string("pgo: ") + pgo_strerror(st) + ": " + pgo_last_error());
+  }
+  // Problem -> device handle (the arrays the residual blocks were recorded into)
+  static pgo_t* Prepare(const Solver::Options& opt, Problem* pr) {
     if (pr->mixed_loss_) throw std::invalid_argument("this backend needs one shared loss for all residual blocks (as main.cpp:68)");
     const int32_t N = (int32_t)pr->ptr_.size(), E = (int32_t)pr->ia_.size();
     std::vector<double> poses((size_t)3 * N);
@@ -165,11 +169,13 @@ struct SolverAccess {
     o.pcg_max_iters = opt.pcg_max_iters;
     o.verbose = opt.minimizer_progress_to_stdout ? 1 : 0;
     pgo_t* h = nullptr;
-    auto check = [](int st) {
-      if (st != PGO_OK) throw std::runtime_error(std::string("pgo: ") + pgo_strerror(st) + ": " + pgo_last_error());
-    };
     check(pgo_create(&h, N, poses.data(), E, pr->ia_.data(), pr->ib_.data(), pr->meas_.data(), pr->kind_.data(), &o, nullptr, opt.device));
-    int st = pgo_solve(h, &sum->s);
+    return h;
+  }
+  // results back into the caller's parameter blocks (in place, like Ceres); destroys the handle
+  static void Finish(Problem* pr, pgo_t* h, int st, Solver::Summary* sum) {
+    const int32_t N = (int32_t)pr->ptr_.size(), E = (int32_t)pr->ia_.size();
+    std::vector<double> poses((size_t)3 * N);
     if (st == PGO_OK) st = pgo_get_poses(h, poses.data());
     std::vector<double> sw((size_t)E, 1.0);
     if (st == PGO_OK && pr->any_sc_) st = pgo_get_switches(h, sw.data(), nullptr);
@@ -179,16 +185,48 @@ struct SolverAccess {
     }
     pgo_destroy(h);
     check(st);
-    for (int32_t i = 0; i < N; ++i)  // in place, like Ceres
+    for (int32_t i = 0; i < N; ++i)
       for (int k = 0; k < 3; ++k) pr->ptr_[i][k] = poses[3 * (size_t)i + k];
     for (int32_t e = 0; e < E; ++e)
       if (pr->switch_[e]) *pr->switch_[e] = sw[(size_t)e];
     sum->num_parameter_blocks = N;
     sum->num_residual_blocks = E;
   }
+  static void Solve(const Solver::Options& opt, Problem* pr, Solver::Summary* sum) {
+    pgo_t* h = Prepare(opt, pr);
+    const int st = pgo_solve(h, &sum->s);
+    Finish(pr, h, st, sum);
+  }
+  // The layer managers' pattern (src/simple_layer_manager.cpp:457-622: one ceres::Solve per candidate layer / window):
+  // independent problems solved concurrently through pgo_solve_batch.
+  static void SolveBatch(const Solver::Options& opt, const std::vector<Problem*>& prs, std::vector<Solver::Summary>* sums,
+                         int max_concurrency) {
+    std::vector<pgo_t*> hs;
+    try {
+      for (Problem* pr : prs) hs.push_back(Prepare(opt, pr));
+    } catch (...) {
+      for (pgo_t* h : hs) pgo_destroy(h);
+      throw;
+    }
+    std::vector<pgo_summary> raw(prs.size());
+    const int st = pgo_solve_batch(hs.data(), (int32_t)hs.size(), raw.data(), max_concurrency);
+    const std::string msg = st != PGO_OK ? std::string(pgo_last_error()) : std::string();
+    sums->assign(prs.size(), Solver::Summary());
+    for (size_t i = 0; i < prs.size(); ++i) {
+      (*sums)[i].s = raw[i];
+      if (st == PGO_OK) Finish(prs[i], hs[i], PGO_OK, &(*sums)[i]);
+      else pgo_destroy(hs[i]);
+    }
+    if (st != PGO_OK) throw std::runtime_error(std::string("pgo: ") + pgo_strerror(st) + ": " + msg);
+  }
 };
 
 inline void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summary) { SolverAccess::Solve(opt, problem, summary); }
+// many independent problems at once; summaries->size() == problems.size() afterwards
+inline void SolveBatch(const Solver::Options& opt, const std::vector<Problem*>& problems, std::vector<Solver::Summary>* summaries,
+                       int max_concurrency = 8) {
+  SolverAccess::SolveBatch(opt, problems, summaries, max_concurrency);
+}
 
 }  // namespace pgo
 
