@@ -784,3 +784,27 @@ def test_host_solve_batch(tmp_path):
     print(p.stdout)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "solve batch ok" in p.stdout and p.stdout.count("layer ") == 6
+
+
+def test_kernel_bench_entry_points(pgo):
+    """pgo_bench_* (what bench.py's roofline figures come from): sane timings and the algorithmic byte counts DESIGN.md
+    section 3 states, for both preconditioner families"""
+    g = pgo.synth_manhattan(60000, 4.0, 0.10, 11)
+    E, N = g.n_edges, g.n_poses
+    for kw, pre_bytes in ((dict(pcg_chain_len=64), 240.0), (dict(pcg_block_poses=4, pcg_chain_len=0), 8.0 * 3 * 12 + 120.0)):
+        s = pgo.Solver(g, pgo.Options(method=1, max_iters=2, pcg_rtol=0.1, pcg_max_iters=100, **kw))
+        with pytest.raises(pgo.PgoError):
+            s.bench_spmv(2)                       # needs a linearisation
+        s.lm_begin()
+        s.lm_step(1)
+        k1, k1c, k2, k3, kp = s.bench_eval(3, True), s.bench_eval(3, False), s.bench_assemble(3), s.bench_spmv(3), s.bench_precond(3)
+        assert k1.units == E and k1.algorithmic_bytes == pytest.approx(196.0 * E)
+        assert k1c.algorithmic_bytes == pytest.approx(92.0 * E)
+        assert k3.units == 2 * E + N and k3.algorithmic_bytes == pytest.approx(76.0 * 2 * E + 124.0 * N)
+        assert kp.units == N and kp.algorithmic_bytes == pytest.approx(pre_bytes * N)
+        for k in (k1, k1c, k2, k3, kp):
+            assert 1e-4 < k.ms_avg < 50.0
+        # timing launches must not disturb the solve
+        done, summ = s.lm_step(1)
+        assert summ.iterations == 2
+        s.close()
