@@ -808,3 +808,23 @@ def test_kernel_bench_entry_points(pgo):
         done, summ = s.lm_step(1)
         assert summ.iterations == 2
         s.close()
+
+
+@pytest.mark.parametrize("kw", [dict(method=2), dict(method=1, info_weighting=1, phi=1.0), dict(method=0)])
+def test_chain_preconditioner_other_modes(pgo, kw):
+    """the preconditioner only sees the assembled system, so METHOD 2 (switches eliminated per edge) and the
+    information-weighted mode run through it unchanged: tight solves agree with the dense-block preconditioner"""
+    g = pgo.synth_manhattan(12000, 4.0, 0.05, 21)
+    base = dict(max_iters=4, pcg_rtol=1e-11, pcg_max_iters=100000, **kw)
+    a = pgo.Solver(g, pgo.Options(pcg_chain_len=64, **base))
+    b = pgo.Solver(g, pgo.Options(pcg_block_poses=4, pcg_chain_len=0, **base))
+    sa, sb = a.solve(), b.solve()
+    assert sa.iterations == sb.iterations == 4
+    assert sa.final_cost == pytest.approx(sb.final_cost, rel=1e-9)
+    assert np.abs(a.poses() - b.poses()).max() < 1e-6
+    for ra, rb in zip(a.iter_records(), b.iter_records()):
+        assert ra["step_ok"] == rb["step_ok"] and ra["cost"] == pytest.approx(rb["cost"], rel=1e-9)
+    if kw.get("method") == 2:
+        assert np.abs(a.switches() - b.switches()).max() < 1e-7
+    print(kw, "PCG iterations chain-64", sa.total_pcg_iters, "dense B=4", sb.total_pcg_iters)
+    a.close(); b.close()
