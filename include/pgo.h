@@ -173,7 +173,9 @@ typedef struct pgo_options {
                                   chunked wavefront scans.  A multiple of 4 that divides 256 (64 = the measured default)
                                   turns it on and overrides pcg_block_poses; 0 = off;
                                   -1 (default) = 64 when pcg_block_poses is 0 (auto) and the graph has > 50000 poses       */
-  int32_t reserved[1];
+  int32_t halo_overlap;        /* 1 (default): with halo_exchange = 1, the exchange runs on a second stream while the SpMV
+                                  multiplies the tiles that reference owned columns only; the tiles that need halo rows
+                                  follow.  0: exchange, then one SpMV launch                                            */
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */

@@ -119,3 +119,26 @@ def test_sharded_info_weighting_and_chi2(tmp_path, world, halo):
         chi2 = np.load(os.path.join(str(tmp_path), "w%dinfo%d" % (world, halo), "chi2_%d.npy" % r))
         np.testing.assert_allclose(chi2, ref_chi2, rtol=1e-6, atol=1e-9)  # evaluated at the solved poses (1e-7 apart)
     assert np.abs(poses[0] - ref_poses[0]).max() < 1e-7
+
+
+@pytest.mark.parametrize("world,chain", [(2, 64), (4, 0)])
+def test_halo_overlap_matches_plain_exchange(tmp_path, world, chain):
+    """halo_overlap = 1 (default): the blocks with owned columns are multiplied (k_spmv MODE 4) while the exchange runs on
+    a second stream, the blocks with remote columns afterwards (k_spmv_remote); 0: exchange, then one SpMV launch.
+    Same LM history either way; also against the 1-rank solve."""
+    base = dict(graph="synth", n_poses=30001, seed=5,
+                options=dict(method=1, max_iters=4, pcg_rtol=0.1, pcg_max_iters=300, pcg_chain_len=chain, halo_exchange=1))
+    ref, ref_poses = run(1, base, tmp_path, tag="ref%d" % chain)
+    out = {}
+    for ov in (0, 1):
+        cfg = dict(base, options=dict(base["options"], halo_overlap=ov))
+        out[ov] = run(world, cfg, tmp_path, tag="ov%dc%d" % (ov, chain))
+    for ov in (0, 1):
+        res, poses = out[ov]
+        for r in range(world):
+            np.testing.assert_array_equal(poses[r], poses[0])
+            for a, b in zip(res[r]["records"], ref[0]["records"]):
+                assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-8)
+                assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 1
+        assert np.abs(poses[0] - ref_poses[0]).max() < 1e-6
+    assert np.abs(out[0][1][0] - out[1][1][0]).max() < 1e-9

@@ -60,7 +60,7 @@ class Options(C.Structure):
                 ("max_lm_diagonal", C.c_double), ("pcg_rtol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("pcg_check_every", C.c_int32), ("verbose", C.c_int32),
                 ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("sc_prior_lambda", C.c_double), ("pose_ordering", C.c_int32), ("info_weighting", C.c_int32),
-                ("pcg_chain_len", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("pcg_chain_len", C.c_int32), ("halo_overlap", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -537,6 +537,8 @@ struct SpmvArgs {
 // 48 (diagonal planes) + 24 (D'D) + 4 (row pointer) + 24 (y) + 24 (p, counted once).
 // MODE 0 = the product kernel.  MODE 1..3 are timing-only ablations used by pgo_bench_spmv under
 // PGO_SPMV_ABLATE (1: no p[col] gather, 2: no H-plane loads, 3: neither): wrong results, same structure.
+// MODE 4 = the part of the product that needs OWNED columns only (blocks whose column lies on another rank contribute
+// 0 and are not loaded): it runs while the halo exchange is in flight, k_spmv_remote adds the rest afterwards.
 template <int MODE>
 __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   // double-buffered staging: ONE barrier per tile (the barrier of tile t+1 orders every wave's row
@@ -579,6 +581,11 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
       if (q < q1) {
         const int64_t col = A.inc_col[q];
         double p0, p1, p2;
+        if (MODE == 4 && (col < A.lo || col >= (int64_t)A.lo + A.n_loc)) {
+          scr[buf][0][tid] = 0.0;
+          scr[buf][1][tid] = 0.0;
+          scr[buf][2][tid] = 0.0;
+        } else {
         if (MODE == 1 || MODE == 3) {
           p0 = (double)col; p1 = p0 + 1.0; p2 = p0 + 2.0;
         } else {
@@ -593,6 +600,7 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
           scr[buf][0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
           scr[buf][1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
           scr[buf][2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
+        }
         }
       }
       __syncthreads();
@@ -627,11 +635,17 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         const int q = base + tid;
         if (q < q1) {
           const int64_t col = A.inc_col[q];
-          const double p0 = A.p[PS * col], p1 = A.p[PS * col + 1], p2 = A.p[PS * col + 2];
-          const double* h = A.hoff + hoff_index(0, q);
-          scr[buf][0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
-          scr[buf][1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
-          scr[buf][2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
+          if (MODE == 4 && (col < A.lo || col >= (int64_t)A.lo + A.n_loc)) {
+            scr[buf][0][tid] = 0.0;
+            scr[buf][1][tid] = 0.0;
+            scr[buf][2][tid] = 0.0;
+          } else {
+            const double p0 = A.p[PS * col], p1 = A.p[PS * col + 1], p2 = A.p[PS * col + 2];
+            const double* h = A.hoff + hoff_index(0, q);
+            scr[buf][0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
+            scr[buf][1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
+            scr[buf][2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
+          }
         }
         __syncthreads();
         if (tid < 3) {
@@ -658,6 +672,49 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   }
   const double tot = block_sum_bcast(dot, red);
   if (tid == 0) A.dot_part[blockIdx.x] = tot;
+}
+
+// The blocks whose column lives on another rank (a few % of a shard's incidences, listed per row at create): after the
+// halo exchange, y_row += sum H_rc p_c and the matching part of p . A p.  One thread per row that has such blocks.
+struct RemoteArgs {
+  const int32_t* rows;     // local rows with remote-column blocks
+  const int32_t* ptr;      // n_rows + 1 into slots
+  const int32_t* slots;    // incidence positions q (the block's place in hoff / inc_col)
+  const int32_t* inc_col;
+  const double* hoff;
+  const double* p;         // gathered vector, global indexing
+  double* y;
+  double* dot_part;
+  int32_t n_rows;
+  int32_t lo;
+  const int32_t* done;
+};
+__global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
+  __shared__ double red[8];
+  if (A.done && *A.done) return;
+  constexpr int64_t S = 64;
+  double dot = 0.0;
+  for (int i = blockIdx.x * WG + threadIdx.x; i < A.n_rows; i += gridDim.x * WG) {
+    const int row = A.rows[i];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+      const int q = A.slots[k];
+      const int64_t col = A.inc_col[q];
+      const double p0 = A.p[PS * col], p1 = A.p[PS * col + 1], p2 = A.p[PS * col + 2];
+      const double* h = A.hoff + hoff_index(0, q);
+      s0 += h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
+      s1 += h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
+      s2 += h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
+    }
+    double* y = A.y + 3 * (int64_t)row;
+    const double* pr = A.p + PS * (int64_t)(A.lo + row);
+    y[0] += s0;
+    y[1] += s1;
+    y[2] += s2;
+    dot += pr[0] * s0 + pr[1] * s1 + pr[2] * s2;
+  }
+  const double tot = block_sum_bcast(dot, red);
+  if (threadIdx.x == 0) A.dot_part[blockIdx.x] = tot;
 }
 
 // ------------------------------------------------------ per-row kernels

@@ -106,6 +106,13 @@ struct pgo_handle {
   int32_t *halo_send_rows = nullptr, *halo_recv_rows = nullptr;
   double *halo_send_buf = nullptr, *halo_recv_buf = nullptr;
   std::vector<int64_t> halo_send_off3, halo_recv_off3;  // offsets in doubles (3 per row)
+  // overlap of the halo exchange with the SpMV (opt.halo_overlap): the blocks with owned columns (MODE 4 of k_spmv) are
+  // multiplied while the exchange runs on a second stream; the few blocks with remote columns follow (k_spmv_remote)
+  bool overlap = false;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+  int32_t *rr_rows = nullptr, *rr_ptr = nullptr, *rr_slots = nullptr;
+  int n_rr = 0, g_spmv_loc = 0, g_rr = 0;
   // METHOD 2: switch variables (one per local edge; only robust edges use theirs), eliminated per edge
   bool has_sw = false;
   double *sw = nullptr, *sw_cand = nullptr, *sw_js = nullptr, *sw_sigma = nullptr, *sw_c = nullptr, *sw_gamma = nullptr,
@@ -140,6 +147,9 @@ struct pgo_handle {
 
   ~pgo_handle() {
     if (device >= 0) (void)hipSetDevice(device);
+    if (ev_pack) (void)hipEventDestroy(ev_pack);
+    if (ev_halo) (void)hipEventDestroy(ev_halo);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
     for (void* p : allocs) (void)hipFree(p);
     if (cg_graph_exec) (void)hipGraphExecDestroy(cg_graph_exec);
     if (h_st) (void)hipHostFree(h_st);
@@ -345,6 +355,58 @@ struct pgo_handle {
     return check_launch("k_spmv");
   }
 
+  // PCG step "make p visible to the peers, then A p" with the halo exchange hidden behind the interior tiles.
+  // *n_part = number of dot partials written to dot_part.
+  int spmv_with_halo(double* full, double* yout, double* dot_part, const int32_t* done, int* n_part) {
+    if (!overlap) {
+      PGOC(share_gather_vector(full));
+      *n_part = g_spmv;
+      return spmv_enqueue(full, yout, dot_part, 1, done);
+    }
+    const int64_t ns = (int64_t)S.halo_send_row.size(), nr = (int64_t)S.halo_recv_row.size();
+    if (ns > 0) {
+      hipLaunchKernelGGL(dev::k_pack_rows, dim3((unsigned)std::min<int64_t>((3 * ns + 255) / 256, 2048)), dim3(256), 0, stream, ns,
+                         (const int32_t*)halo_send_rows, (const double*)full, halo_send_buf);
+      PGOC(check_launch("k_pack_rows"));
+    }
+    HIPC(hipEventRecord(ev_pack, stream));
+    int used = 0;
+    if (S.n_tiles() > 0) {  // enqueued before the exchange so that it also overlaps a host-blocking back-end
+      dev::SpmvArgs A = spmv_args(full, yout, dot_part, 1, done);
+      hipLaunchKernelGGL(dev::k_spmv_t<4>, dim3(g_spmv_loc), dim3(dev::WG), 0, stream, A);
+      PGOC(check_launch("k_spmv (owned columns)"));
+      used += g_spmv_loc;
+    }
+    HIPC(hipStreamWaitEvent(comm_stream, ev_pack, 0));
+    PGOC(comm->exchange(halo_send_buf, halo_send_off3.data(), halo_recv_buf, halo_recv_off3.data(), comm_stream));
+    if (nr > 0) {
+      hipLaunchKernelGGL(dev::k_unpack_rows, dim3((unsigned)std::min<int64_t>((3 * nr + 255) / 256, 2048)), dim3(256), 0, comm_stream, nr,
+                         (const int32_t*)halo_recv_rows, (const double*)halo_recv_buf, full);
+      PGOC(check_launch("k_unpack_rows"));
+    }
+    HIPC(hipEventRecord(ev_halo, comm_stream));
+    HIPC(hipStreamWaitEvent(stream, ev_halo, 0));
+    if (n_rr > 0) {
+      dev::RemoteArgs R;
+      R.rows = rr_rows;
+      R.ptr = rr_ptr;
+      R.slots = rr_slots;
+      R.inc_col = inc_col;
+      R.hoff = hoff;
+      R.p = full;
+      R.y = yout;
+      R.dot_part = dot_part + used;
+      R.n_rows = n_rr;
+      R.lo = S.lo;
+      R.done = done;
+      hipLaunchKernelGGL(dev::k_spmv_remote, dim3(g_rr), dim3(dev::WG), 0, stream, R);
+      PGOC(check_launch("k_spmv_remote"));
+      used += g_rr;
+    }
+    *n_part = used;
+    return PGO_OK;
+  }
+
   dev::CgVec cg_vec() const {
     dev::CgVec V;
     V.n_loc = S.n_loc;
@@ -519,6 +581,32 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       halo_send_off3[k] = 3 * S.halo_send_off[k];
       halo_recv_off3[k] = 3 * S.halo_recv_off[k];
     }
+    if (opt.halo_overlap != 0 && S.n_tiles() > 0) {
+      std::vector<int32_t> rows, ptr(1, 0), slots;
+      for (int32_t r = 0; r < S.n_loc; ++r) {
+        const size_t before = slots.size();
+        for (int32_t q = S.inc_ptr[r]; q < S.inc_ptr[r + 1]; ++q)
+          if (S.inc_col[q] < S.lo || S.inc_col[q] >= S.hi) slots.push_back(q);
+        if (slots.size() > before) {
+          rows.push_back(r);
+          ptr.push_back((int32_t)slots.size());
+        }
+      }
+      n_rr = (int)rows.size();
+      PGOC(dalloc(&rr_rows, std::max<int64_t>(1, n_rr)));
+      PGOC(dalloc(&rr_ptr, (int64_t)ptr.size()));
+      PGOC(dalloc(&rr_slots, std::max<int64_t>(1, (int64_t)slots.size())));
+      PGOC(upload(rr_rows, rows));
+      PGOC(upload(rr_ptr, ptr));
+      PGOC(upload(rr_slots, slots));
+      PGOC(sync());  // the lists die with this scope
+      g_spmv_loc = up8(std::min(std::max(1, S.n_tiles()), 1536));  // + g_rr <= 2048 partials
+      g_rr = std::min(std::max(1, (n_rr + dev::WG - 1) / dev::WG), 512);
+      HIPC(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+      HIPC(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
+      HIPC(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+      overlap = true;
+    }
   }
   // preconditioner block size
   if (grp_B > 1 && NL > 0) {
@@ -689,15 +777,17 @@ int pgo_handle::pcg(int* iters, double* rel) {
   PGOC(reduce_to_scal({{part[0], g_u1, 0}, {part[1], g_u1, 0}}, 4));
   hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
   PGOC(check_launch("k_cg_init_fin"));
-  PGOC(share_gather_vector(p_full));
+  if (!overlap) PGOC(share_gather_vector(p_full));
   const int max_it = std::max(0, opt.pcg_max_iters);
   int every = std::max(1, opt.pcg_check_every);
   // one PCG iteration = 3 dependent launches; `par` is the r.z double-buffer parity baked into the arguments
   auto enqueue_iteration = [&](int par) -> int {
-    PGOC(spmv_enqueue(p_full, ap, part[0], 1, &st->done));
+    int n_sp = g_spmv;
+    if (overlap) PGOC(spmv_with_halo(p_full, ap, part[0], &st->done, &n_sp));  // p reaches the peers inside
+    else PGOC(spmv_enqueue(p_full, ap, part[0], 1, &st->done));
     const double* pap = multi ? scal + 6 : part[0];
-    const int n_pap = multi ? 1 : g_spmv;
-    if (multi) PGOC(reduce_to_scal({{part[0], g_spmv, 0}}, 6));
+    const int n_pap = multi ? 1 : n_sp;
+    if (multi) PGOC(reduce_to_scal({{part[0], n_sp, 0}}, 6));
     if (chained) hipLaunchKernelGGL(dev::k_cg_update1_c, dim3(g_u1), dim3(dev::WG), 0, stream, V, CP, par, pap, n_pap, part[1], part[2]);
     else if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, par, pap, n_pap, part[1], part[2]);
     else hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_u1), dim3(dev::WG), 0, stream, V, par, pap, n_pap, part[1], part[2]);
@@ -706,7 +796,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
       PGOC(reduce_to_scal({{part[1], g_u1, 0}, {part[2], g_u1, 0}}, 7));
       hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
       PGOC(check_launch("k_cg_update2"));
-      PGOC(share_gather_vector(p_full));
+      if (!overlap) PGOC(share_gather_vector(p_full));
     } else {
       hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_u1, part[2], g_u1);
       PGOC(check_launch("k_cg_update2"));
@@ -1003,6 +1093,7 @@ void pgo_options_default(pgo_options* o) {
   o->sc_prior_lambda = 1.0;
   o->pose_ordering = -1;
   o->pcg_chain_len = -1;
+  o->halo_overlap = 1;
 }
 
 int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
