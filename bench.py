@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--pcg-rtol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=500)
     ap.add_argument("--pcg-block-poses", type=int, default=0, help="poses per dense block-Jacobi block, 0 = auto (GPU and CPU baseline)")
+    ap.add_argument("--pcg-check-every", type=int, default=100,
+                    help="PCG iterations enqueued (as one hipGraph replay at 1 GPU) between two host checks of the convergence flag")
     ap.add_argument("--pcg-chain-len", type=int, default=-1,
                     help="chain (block-tridiagonal) preconditioner over segments of 64 poses: 64 = on, 0 = off, -1 = auto (GPU and CPU baseline)")
     ap.add_argument("--halo-exchange", type=int, default=1, help="N > 1: 1 = point-to-point halo exchange of the search direction, 0 = all-gather")
@@ -98,7 +100,7 @@ def main():
     opt = P.Options(method=1, max_iters=W + K, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0, pcg_rtol=args.pcg_rtol,
                     pcg_max_iters=args.pcg_max_iters, pcg_block_poses=args.pcg_block_poses, pcg_chain_len=args.pcg_chain_len,
                     halo_exchange=args.halo_exchange,
-                    pcg_check_every=min(100, max(1, args.pcg_max_iters)), verbose=args.verbose if rank == 0 else 0)
+                    pcg_check_every=min(max(1, args.pcg_check_every), max(1, args.pcg_max_iters)), verbose=args.verbose if rank == 0 else 0)
     # the preconditioner the library resolves for these options (pgo_internal.h resolve_chain_len / resolve_block_poses)
     chain = args.pcg_chain_len if args.pcg_chain_len >= 0 else (64 if (args.pcg_block_poses <= 0 and g.n_poses > 50000) else 0)
     blockp = args.pcg_block_poses if args.pcg_block_poses > 0 else (32 if g.n_poses <= 8192 else 4)

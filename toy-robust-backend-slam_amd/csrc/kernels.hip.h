@@ -1157,11 +1157,15 @@ struct ChainPre {
   int32_t n_pad;      // n_loc rounded up to whole 256-row tiles
 };
 
-// C_i: sum of the off-diagonal blocks (i, i-1) of row i (9 planes, natural order); 0 at a segment start
+// Input record of the factorisation, one 128-byte line per row: M_ii = H_ii + D'D (6: 00 01 02 11 12 22) | C_i = the sum
+// of the off-diagonal blocks (i, i-1) of row i, row-major (9; 0 at a segment start) | pad.  One thread per row.
+constexpr int CHAIN_REC = 16;
 __global__ void k_chain_extract(const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_col,
-                                const double* __restrict__ hoff, int n_loc, int lo, int seg_len, double* __restrict__ cc) {
+                                const double* __restrict__ hoff, const double* __restrict__ hd, const double* __restrict__ d2,
+                                int n_loc, int lo, int seg_len, double* __restrict__ rec) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_loc) return;
+  const int64_t n = n_loc;
   double acc[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if ((row % seg_len) != 0) {
     const int target = lo + row - 1;
@@ -1171,13 +1175,21 @@ __global__ void k_chain_extract(const int32_t* __restrict__ inc_ptr, const int32
         for (int c = 0; c < 9; ++c) acc[c] += hoff[hoff_index(c, q)];
       }
   }
-#pragma unroll
-  for (int c = 0; c < 9; ++c) cc[(int64_t)c * n_loc + row] = acc[c];
+  double2* out = reinterpret_cast<double2*>(rec + (int64_t)row * CHAIN_REC);
+  out[0] = make_double2(hd[row] + d2[3 * (int64_t)row], hd[n + row]);
+  out[1] = make_double2(hd[2 * n + row], hd[3 * n + row] + d2[3 * (int64_t)row + 1]);
+  out[2] = make_double2(hd[4 * n + row], hd[5 * n + row] + d2[3 * (int64_t)row + 2]);
+  out[3] = make_double2(acc[0], acc[1]);
+  out[4] = make_double2(acc[2], acc[3]);
+  out[5] = make_double2(acc[4], acc[5]);
+  out[6] = make_double2(acc[6], acc[7]);
+  out[7] = make_double2(acc[8], 0.0);
 }
 
-// one thread per segment, sequential along the chain (seg_len dependent 3x3 steps; once per LM iteration)
-__global__ void k_chain_factor(const double* __restrict__ hd, const double* __restrict__ d2, const double* __restrict__ cc,
-                               int n_loc, int n_pad, int seg_len, double* __restrict__ cw, double* __restrict__ cs) {
+// one thread per segment, sequential along the chain (seg_len dependent 3x3 steps; once per LM iteration); each step
+// reads one 128-byte record
+__global__ void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len, double* __restrict__ cw,
+                               double* __restrict__ cs) {
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = n_loc, np = n_pad;
   const int64_t s0 = (int64_t)seg * seg_len;
@@ -1185,13 +1197,12 @@ __global__ void k_chain_factor(const double* __restrict__ hd, const double* __re
   const int64_t s1 = s0 + seg_len < n ? s0 + seg_len : n;
   double p00 = 0.0, p01 = 0.0, p02 = 0.0, p11 = 0.0, p12 = 0.0, p22 = 0.0;  // S_{i-1}^-1
   for (int64_t i = s0; i < s1; ++i) {
-    double a00 = hd[i] + d2[3 * i], a01 = hd[n + i], a02 = hd[2 * n + i], a11 = hd[3 * n + i] + d2[3 * i + 1],
-           a12 = hd[4 * n + i], a22 = hd[5 * n + i] + d2[3 * i + 2];
+    const double2* in = reinterpret_cast<const double2*>(rec + i * CHAIN_REC);
+    const double2 v0 = in[0], v1 = in[1], v2 = in[2], v3 = in[3], v4 = in[4], v5 = in[5], v6 = in[6], v7 = in[7];
+    double a00 = v0.x, a01 = v0.y, a02 = v1.x, a11 = v1.y, a12 = v2.x, a22 = v2.y;
     double W[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (i > s0) {
-      double C[9];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) C[c] = cc[(int64_t)c * n + i];
+      const double C[9] = {v3.x, v3.y, v4.x, v4.y, v5.x, v5.y, v6.x, v6.y, v7.x};
 #pragma unroll
       for (int a = 0; a < 3; ++a) {  // W = C S_{i-1}^-1
         W[3 * a] = C[3 * a] * p00 + C[3 * a + 1] * p01 + C[3 * a + 2] * p02;

@@ -627,7 +627,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   }
   if (chain_len && NL > 0) {
     chain_pad = (int)(((NL + dev::CHAIN_TILE - 1) / dev::CHAIN_TILE) * dev::CHAIN_TILE);
-    PGOC(dalloc(&chain_c, 9 * NL));
+    PGOC(dalloc(&chain_c, (int64_t)dev::CHAIN_REC * NL));
     PGOC(dalloc(&chain_w, 9 * (int64_t)chain_pad));
     PGOC(dalloc(&chain_s, 6 * (int64_t)chain_pad));
     // the padding rows of the factor planes are never written: they must read as 0
@@ -892,11 +892,11 @@ int pgo_handle::lm_iteration(bool* stop) {
   }
   if (chain_len) {
     hipLaunchKernelGGL(dev::k_chain_extract, dim3(g_rows), dim3(dev::WG), 0, stream, (const int32_t*)inc_ptr, (const int32_t*)inc_col,
-                       (const double*)hoff, S.n_loc, S.lo, chain_len, chain_c);
+                       (const double*)hoff, (const double*)hd, (const double*)d2, S.n_loc, S.lo, chain_len, chain_c);
     PGOC(check_launch("k_chain_extract"));
     const int n_seg = (S.n_loc + chain_len - 1) / chain_len;
-    hipLaunchKernelGGL(dev::k_chain_factor, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)hd, (const double*)d2,
-                       (const double*)chain_c, S.n_loc, chain_pad, chain_len, chain_w, chain_s);
+    hipLaunchKernelGGL(dev::k_chain_factor, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc,
+                       chain_pad, chain_len, chain_w, chain_s);
     PGOC(check_launch("k_chain_factor"));
   }
   int k_it = 0;
