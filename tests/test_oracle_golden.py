@@ -307,3 +307,21 @@ def test_info_mode_fixture_regression(oracle):
     # the C port (PCG) follows the same trajectory in this mode too
     port = oracle.lm_pcg(gm, oracle.Options(method=0, info_weighting=1, phi=1.0, max_iters=10, pcg_rtol=1e-12, pcg_block_poses=32))
     assert port.records[10]["cost"] == pytest.approx(f["records"][10]["cost"], rel=1e-6)
+
+
+def test_lm_pcg_port_chain_preconditioner(oracle):
+    """the chain (block-tridiagonal segments) preconditioner of the port: same LM trajectory as the 3x3 blocks when PCG
+    is run tight (a preconditioner must not change what is solved), fewer PCG iterations, for several segment lengths
+    including one that does not divide the pose count"""
+    g = oracle.read_g2o(os.path.join(DATA, "INTEL.g2o"))
+    g = oracle.add_random_C(g, 20, 2)
+    base = dict(method=1, max_iters=5, pcg_rtol=1e-12, pcg_max_iters=200000, threads=4)
+    ref = oracle.lm_pcg(g, oracle.Options(pcg_block_poses=1, **base))
+    for L in (8, 64, 100):
+        res = oracle.lm_pcg(g, oracle.Options(pcg_chain_len=L, **base))
+        assert res.total_pcg_iters < 0.5 * ref.total_pcg_iters
+        for a, b in zip(res.records, ref.records):
+            assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-8)
+        assert np.abs(res.poses - ref.poses).max() < 1e-7
+    direct = oracle.lm_direct(g, oracle.Options(method=1, max_iters=5))
+    assert np.abs(ref.poses - direct.poses).max() < 1e-6
