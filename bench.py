@@ -110,16 +110,36 @@ def main():
     s = P.Solver(g, opt, comm, device=local_rank)
     t_create = time.time() - t_create
 
+    x0 = np.array(g.poses)
     s.lm_begin()
     if W > 0:
         s.lm_step(W)
+    recs = s.iter_records()
+    n_prev = sum(1 for r in recs if r["iter"] > 0)
     barrier()
     t0 = time.perf_counter()
-    done, summ = s.lm_step(K)
+    # exactly K LM iterations.  The minimiser can stop before max_iters = W + K only through MIN_RADIUS or FAILURE (a
+    # non-finite Jacobian at an accepted point: the reference's asin' singularity at |sin delta| = 1); it is then restarted
+    # from the initial poses INSIDE the timed region so that K iterations are always what is timed.
+    timed, restarts = [], 0
+    while len(timed) < K:
+        done, summ = s.lm_step(K - len(timed))
+        now = s.iter_records()
+        n_now = sum(1 for r in now if r["iter"] > 0)
+        new = now[len(now) - (n_now - n_prev):] if n_now > n_prev else []
+        if restarts == 0:
+            recs = now
+        timed += new
+        n_prev = n_now
+        if len(timed) < K:
+            restarts += 1
+            if restarts > 8 and not new:
+                raise RuntimeError("bench: the solver makes no progress: %r" % (summ.as_dict(),))
+            s.set_poses(x0)
+            s.lm_begin()
+            n_prev = 0
     barrier()
     dt = time.perf_counter() - t0
-    recs = s.iter_records()
-    timed = [r for r in recs if r["iter"] > W]
     assert len(timed) == K, (len(timed), K, summ.as_dict())
 
     # kernel-level numbers, measured live with HIP events on the solver's stream
@@ -165,6 +185,7 @@ def main():
             "pcg_iters_per_step": sum(r["pcg_iters"] for r in timed) / K,
             "accepted_steps": sum(1 for r in timed if r["step_ok"] == 1),
             "cost_first_last": [recs[0]["cost"], summ.final_cost],
+            "restarts": restarts,
             "roofline": {
                 "kernel": "k_spmv (block-CSR 3x3 SpMV, fp64)",
                 "bound": "hbm",
