@@ -172,7 +172,8 @@ typedef struct pgo_options {
                                   adds its 3x3 diagonal blocks), factorised exactly per LM iteration and applied by
                                   chunked wavefront scans.  A multiple of 4 that divides 256 (64 = the measured default)
                                   turns it on and overrides pcg_block_poses; 0 = off;
-                                  -1 (default) = 64 when pcg_block_poses is 0 (auto) and the graph has > 50000 poses       */
+                                  -1 (default), with pcg_block_poses = 0 (auto): 64 on graphs of > 50000 poses; 256 on chain-like
+                                  graphs of 512..8192 poses (few short-range non-consecutive edges); else off                 */
   int32_t halo_overlap;        /* 1 (default): with halo_exchange = 1, the exchange runs on a second stream while the SpMV
                                   multiplies the tiles that reference owned columns only; the tiles that need halo rows
                                   follow.  0: exchange, then one SpMV launch                                            */

@@ -29,6 +29,8 @@ def main():
         g = P.ReadG2O(os.path.join(ROOT, "tests", "golden", "data", name + ".g2o"))
         if n_out:
             g.add_random_C(n_out, 1)
+        d = np.abs(np.array(g.ia).astype(np.int64) - np.array(g.ib).astype(np.int64))
+        chain_like = 20 * int(((d >= 2) & (d < 32)).sum()) <= g.n_poses      # pgo_internal.h resolve_chain_len
         s = P.Solver(g, P.Options(method=method, pcg_max_iters=200000))
         s.solve()  # warm-up (graph capture, clocks)
         s.set_poses(np.array(g.poses))
@@ -41,7 +43,7 @@ def main():
         ores = O.lm_direct_sc(og(g), O.Options(method=2)) if method == 2 else O.lm_direct(og(g), O.Options(method=method))
         odt = time.perf_counter() - t
         rows.append(dict(workload="%s +%d outliers, METHOD %d" % (name, n_out, method), poses=g.n_poses, edges=g.n_edges,
-                         policy="exact (PCG rtol 1e-10, 32-pose blocks)", lm_iters=summ.iterations, pcg_iters=summ.total_pcg_iters,
+                         policy="exact (PCG rtol 1e-10, %s)" % ("256-pose chain segments" if chain_like else "32-pose blocks"), lm_iters=summ.iterations, pcg_iters=summ.total_pcg_iters,
                          gpu_s=dt, gpu_it_s=summ.iterations / dt, cpu_kind="oracle lm_direct (scipy SuperLU + C eval, 1 thread)",
                          cpu_s=odt, cpu_it_s=ores.iterations / odt, final_cost_gpu=summ.final_cost, final_cost_cpu=ores.final_cost,
                          max_dxy=float(np.abs(x[:, :2] - ores.poses[:, :2]).max())))

@@ -8,10 +8,10 @@ for name, n_out, method in [("INTEL", 50, 1), ("INTEL", 50, 0), ("INTEL", 50, 2)
     g = P.ReadG2O(os.path.join(ROOT, "tests", "golden", "data", name + ".g2o"))
     if n_out: g.add_random_C(n_out, 1)
     out = []
-    for tag, kw in (("B32", dict(pcg_block_poses=32, pcg_chain_len=0)), ("chain", dict(pcg_chain_len=64))):
+    for tag, kw in (("B32", dict(pcg_block_poses=32, pcg_chain_len=0)), ("chain64", dict(pcg_chain_len=64)), ("chain256", dict(pcg_chain_len=256))):
         s = P.Solver(g, P.Options(method=method, pcg_max_iters=400000, **kw))
         s.solve(); s.set_poses(np.array(g.poses))
         t = time.perf_counter(); summ = s.solve(); dt = time.perf_counter() - t
-        out.append("%s: %.3f s %6d pcg cost %.9g" % (tag, dt, summ.total_pcg_iters, summ.final_cost))
+        out.append("%s: %.3f s %6d pcg" % (tag, dt, summ.total_pcg_iters))
         s.close()
     print("%-6s +%2d m%d  " % (name, n_out, method) + "   ".join(out), flush=True)

@@ -92,12 +92,28 @@ inline int resolve_block_poses(int opt_value, int32_t n_poses) {
   return b > 32 ? 32 : b;
 }
 
-// segment length of the chain (block-tridiagonal) preconditioner for an option value: -1 = auto (64 on graphs of more
-// than 50000 poses when the block size is also left to auto), 0 = off.  Measured GN it/s, chain-64 vs dense blocks:
-// 1M poses 47.6 vs 36.4, 100k 328 vs 303, 10k 401 vs 594 (a wavefront covers 256 poses: too few waves on small graphs)
-inline int resolve_chain_len(int opt_value, int opt_block_poses, int32_t n_poses) {
-  if (opt_value < 0) return (opt_block_poses <= 0 && n_poses > 50000) ? 64 : 0;
-  return opt_value;
+// segment length of the chain (block-tridiagonal) preconditioner for an option value: 0 = off, -1 = auto when the block
+// size is also left to auto:
+//   * more than 50000 poses: 64.  Measured GN it/s, chain-64 vs dense blocks: 1M poses 47.6 vs 36.4, 100k 328 vs 303,
+//     10k 401 vs 594 (a wavefront covers 256 poses: too few waves on mid-size graphs);
+//   * up to 8192 poses (launch-bound, exact mode): 256 if the graph is chain-like -- at most 5 % as many SHORT-RANGE
+//     non-consecutive edges (2 <= |a-b| < 32) as poses -- else off (dense 32-pose blocks, which capture such edges; the
+//     tridiagonal chain does not).  Measured, 50 LM iterations, chain-256 vs B=32: INTEL 0.40 vs 0.48 s, MIT METHOD 1
+//     0.21 vs 1.42 s, CSAIL 0.44 vs 0.46, FR079 0.41 vs 0.45; FRH 2.07 vs 0.46 and M3500 2.25 vs 1.20 (short-range rich).
+inline int resolve_chain_len(int opt_value, int opt_block_poses, int32_t n_poses, int32_t n_edges = 0,
+                             const int32_t* ia = nullptr, const int32_t* ib = nullptr) {
+  if (opt_value >= 0) return opt_value;
+  if (opt_block_poses > 0) return 0;
+  if (n_poses > 50000) return 64;
+  if (n_poses <= 8192 && n_poses >= 512 && ia && ib) {
+    int64_t short_range = 0;
+    for (int32_t e = 0; e < n_edges; ++e) {
+      const int32_t d = ia[e] > ib[e] ? ia[e] - ib[e] : ib[e] - ia[e];
+      short_range += (d >= 2 && d < 32);
+    }
+    if (20 * short_range <= (int64_t)n_poses) return 256;
+  }
+  return 0;
 }
 
 }  // namespace pgo

@@ -458,7 +458,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   const char* fc = getenv("PGO_FORCE_COLLECTIVES");
   force_collectives = fc && fc[0] == '1';
   grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
-  chain_len = pgo::resolve_chain_len(opt.pcg_chain_len, opt.pcg_block_poses, N);
+  chain_len = pgo::resolve_chain_len(opt.pcg_chain_len, opt.pcg_block_poses, N, E, ia, ib);
   if (chain_len != 0 && (chain_len < dev::CHAIN_CHUNK || chain_len % dev::CHAIN_CHUNK != 0 || dev::CHAIN_TILE % chain_len != 0))
     return fail(PGO_ERR_INVALID_ARG, "pcg_chain_len: a multiple of 4 that divides 256 (4 ... 256), 0 = off, -1 = auto");
   if (chain_len) grp_B = 1;
