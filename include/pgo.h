@@ -301,6 +301,7 @@ typedef struct pgo_kernel_stats {
 int pgo_bench_eval(pgo_t* h, int reps, int with_jacobian, pgo_kernel_stats* out); /* [gpu] K1 */
 int pgo_bench_assemble(pgo_t* h, int reps, pgo_kernel_stats* out);                /* [gpu] K2 */
 int pgo_bench_spmv(pgo_t* h, int reps, pgo_kernel_stats* out);                    /* [gpu] K3 */
+int pgo_debug_precond(pgo_t* h, const double* r_3n, double* z_3n);               /* [gpu] z = M^-1 r, current preconditioner */
 int pgo_bench_precond(pgo_t* h, int reps, pgo_kernel_stats* out);                 /* [gpu] z = M^-1 b as the PCG start-up kernel */
 /* y = (J'J + D'D) x in the scaled space at the current linearisation, with the
  * current LM diagonal; x,y: 3N doubles (world == 1).  For SpMV parity tests.    */

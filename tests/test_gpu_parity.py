@@ -828,3 +828,29 @@ def test_chain_preconditioner_other_modes(pgo, kw):
         assert np.abs(a.switches() - b.switches()).max() < 1e-7
     print(kw, "PCG iterations chain-64", sa.total_pcg_iters, "dense B=4", sb.total_pcg_iters)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n_poses,kw", [(1000000, dict(pcg_chain_len=64)), (30011, dict(pcg_chain_len=256)),
+                                        (30011, dict(pcg_block_poses=4, pcg_chain_len=0)), (30011, dict(pcg_block_poses=1, pcg_chain_len=0))])
+def test_preconditioner_is_symmetric_positive_definite(pgo, n_poses, kw):
+    """what CG needs from M^-1, checked through the apply kernels themselves (k_cg_init_c: chunked wave scans over the
+    block LDL' factors; k_cg_init_g: dense group inverses) at the bench size and on a ragged graph:
+    u'(M^-1 v) == v'(M^-1 u), r'(M^-1 r) > 0, linearity, and the constant pose's rows stay decoupled"""
+    g = pgo.synth_manhattan(n_poses, 4.0, 0.10, 20260410)
+    s = pgo.Solver(g, pgo.Options(method=1, max_iters=2, pcg_rtol=0.1, pcg_max_iters=50, **kw))
+    s.lm_begin()
+    s.lm_step(2)
+    rng = np.random.default_rng(12)
+    n = 3 * g.n_poses
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+    Mu, Mv = s.precond(u), s.precond(v)
+    assert np.isfinite(Mu).all() and np.isfinite(Mv).all()
+    a, b = float(u @ Mv), float(v @ Mu)
+    assert a == pytest.approx(b, rel=1e-10, abs=1e-10 * np.sqrt(float(u @ Mu) * float(v @ Mv)))
+    assert float(u @ Mu) > 0.0 and float(v @ Mv) > 0.0
+    np.testing.assert_allclose(s.precond(2.0 * u - 3.0 * v), 2.0 * Mu - 3.0 * Mv, rtol=1e-9, atol=1e-9 * np.abs(Mu).max())
+    e = np.zeros(n); e[0:3] = (1.0, -2.0, 0.5)          # the constant pose: identity LM row, nothing else
+    z = s.precond(e)
+    np.testing.assert_allclose(z[0:3], e[0:3], rtol=1e-12)
+    assert np.abs(z[3:]).max() == 0.0
+    s.close()

@@ -39,7 +39,7 @@ EXPORTS = [
     "pgo_create", "pgo_create_weighted", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_edge_chi2", "pgo_solve", "pgo_solve_batch", "pgo_lm_begin", "pgo_lm_step",
     "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
     "pgo_write_switches",
-    "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_bench_precond", "pgo_debug_spmv", "pgo_debug_normal_eq",
+    "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_bench_precond", "pgo_debug_precond", "pgo_debug_spmv", "pgo_debug_normal_eq",
     "pgo_shard_plan", "pgo_shard_halo", "pgo_pose_order",
 ]
 
@@ -171,6 +171,7 @@ def lib():
     L.pgo_bench_assemble.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
     L.pgo_bench_spmv.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
     L.pgo_bench_precond.argtypes = [vp, C.c_int, C.POINTER(KernelStats)]
+    L.pgo_debug_precond.argtypes = [vp, dp, dp]
     L.pgo_debug_spmv.argtypes = [vp, dp, dp]
     L.pgo_debug_normal_eq.argtypes = [vp, dp, dp]
     L.pgo_shard_plan.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
@@ -496,6 +497,13 @@ class Solver:
         k = KernelStats()
         _check(lib().pgo_bench_spmv(self._h, reps, C.byref(k)))
         return k
+
+    def precond(self, r):
+        """z = M^-1 r with the current preconditioner (debug / property tests)"""
+        r = np.ascontiguousarray(r, np.float64)
+        z = np.zeros_like(r)
+        _check(lib().pgo_debug_precond(self._h, _dp(r), _dp(z)))
+        return z
 
     def bench_precond(self, reps=10) -> KernelStats:
         k = KernelStats()

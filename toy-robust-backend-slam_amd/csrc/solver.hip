@@ -1410,6 +1410,49 @@ int pgo_debug_spmv(pgo_t* h, const double* x, double* yout) {
   return PGO_OK;
 }
 
+// z = M^-1 r with the preconditioner of the current LM iteration (whatever family the handle resolved to), through the
+// PCG start-up kernel: for the symmetry / positivity property tests.  Needs at least one LM iteration; world == 1.
+int pgo_debug_precond(pgo_t* h, const double* r_in, double* z_out) {
+  if (!h || !r_in || !z_out) return fail(PGO_ERR_INVALID_ARG, "pgo_debug_precond: null");
+  if (h->comm && h->comm->world > 1) return fail(PGO_ERR_UNSUPPORTED, "world == 1 only");
+  if (!h->lin_valid || h->iter < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_debug_precond: run at least one LM iteration first");
+  HIPC(hipSetDevice(h->device));
+  const int64_t N = h->S.n_poses;
+  std::vector<double> tmp;
+  const double* src = r_in;
+  if (!h->perm.empty()) {
+    h->to_internal(r_in, &tmp, 3);
+    src = tmp.data();
+  }
+  HIPC(hipMemcpyAsync(h->ap, src, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));  // ap: scratch input
+  dev::CgVec V = h->cg_vec();
+  if (h->chain_len) {
+    dev::ChainPre CP;
+    CP.cw = h->chain_w;
+    CP.cs = h->chain_s;
+    CP.n_loc = h->S.n_loc;
+    CP.n_pad = h->chain_pad;
+    hipLaunchKernelGGL(dev::k_cg_init_c, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->ap, h->part[0], h->part[1]);
+  } else if (h->grp_B > 1) {
+    dev::GroupPre GP;
+    GP.ginv = h->ginv;
+    GP.B = h->grp_B;
+    GP.nb = h->grp_nb;
+    GP.nb_pad = h->grp_pad;
+    GP.n_groups = h->n_groups;
+    hipLaunchKernelGGL(dev::k_cg_init_g, dim3(h->g_grp), dim3(dev::WG), 0, h->stream, V, GP, (const double*)h->ap, h->part[0], h->part[1]);
+  } else {
+    hipLaunchKernelGGL(dev::k_cg_init, dim3(h->g_vec), dim3(dev::WG), 0, h->stream, V, (const double*)h->ap, h->part[0], h->part[1]);
+  }
+  PGOC(h->check_launch("k_cg_init (debug)"));
+  std::vector<double> ztmp((size_t)3 * N);
+  HIPC(hipMemcpyAsync(ztmp.data(), h->z, ztmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PGOC(h->sync());
+  if (h->perm.empty()) memcpy(z_out, ztmp.data(), ztmp.size() * sizeof(double));
+  else h->to_caller(ztmp, z_out, 3);
+  return PGO_OK;
+}
+
 static int time_launches(pgo_handle* h, int reps, const std::function<void()>& launch, double* ms_avg) {
   hipEvent_t e0, e1;
   HIPC(hipEventCreate(&e0));
