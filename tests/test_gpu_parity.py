@@ -282,7 +282,7 @@ def test_lm_inexact_matches_port_on_synthetic_10k(pgo, oracle):
     s.close()
 
 
-@pytest.mark.parametrize("n_poses,seed,chain", [(10000, 20260410, 64), (30011, 3, 64), (30011, 3, 256), (9001, 4, 8)])
+@pytest.mark.parametrize("n_poses,seed,chain", [(10000, 20260410, 64), (30011, 3, 64), (30011, 3, 256), (9001, 4, 8), (150, 7, 64)])
 def test_chain_preconditioner_matches_port(pgo, oracle, n_poses, seed, chain):
     """pcg_chain_len: block-tridiagonal segments, factor (k_chain_factor) + chunked wave-scan apply (k_cg_update1_c)
     against the sequential block LDL' sweep of the C port: same LM history, PCG iteration counts within 1, and fewer PCG
