@@ -42,7 +42,59 @@ constexpr int PS = 3;            // doubles per pose in the GATHERED vector p.  
 // AoSoA: incidences in groups of 64 (one wave), 9 values x 64 lanes contiguous (4608 B per group), so
 // that a wave's 9 coalesced 512-byte accesses fall into ONE contiguous 4.5 KiB region instead of nine
 // regions tens of MB apart (DRAM page locality; measured against plain planes).
-__device__ __forceinline__ int64_t hoff_index(int c, int64_t q) { return (q >> 6) * 576 + (int64_t)c * 64 + (q & 63); }
+//
+// Inside a group the first eight values are stored as four (2 x 64) double2 planes and the ninth as one 64-double plane:
+// a lane moves its block with four 16-byte accesses + one 8-byte access (8-byte-per-lane streams run at 0.54-0.70x the
+// rate of 16-byte ones on gfx950, MI355X_MICROARCH.md "cache-policy bits"); value c of incidence q sits at hoff_index(c, q).
+__device__ __forceinline__ int64_t hoff_index(int c, int64_t q) {
+  const int64_t g = (q >> 6) * 576, l = q & 63;
+  return c < 8 ? g + (int64_t)(c >> 1) * 128 + 2 * l + (c & 1) : g + 512 + l;
+}
+// the whole block of incidence q (row-major 3x3) in / out of registers
+__device__ __forceinline__ void hoff_load(const double* __restrict__ hoff, int64_t q, double (&v)[9]) {
+  const double* g = hoff + (q >> 6) * 576;
+  const int l = (int)(q & 63);
+  const double2* g2 = reinterpret_cast<const double2*>(g) + l;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double2 t = g2[64 * k];
+    v[2 * k] = t.x;
+    v[2 * k + 1] = t.y;
+  }
+  v[8] = g[512 + l];
+}
+// the same with the non-temporal hint: the H stream is read once per product and should not displace the gathered
+// search direction from L2
+typedef double double2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void hoff_load_nt(const double* __restrict__ hoff, int64_t q, double (&v)[9]) {
+  const double* g = hoff + (q >> 6) * 576;
+  const int l = (int)(q & 63);
+  const double2_v* g2 = reinterpret_cast<const double2_v*>(g) + l;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double2_v t = __builtin_nontemporal_load(g2 + 64 * k);
+    v[2 * k] = t.x;
+    v[2 * k + 1] = t.y;
+  }
+  v[8] = __builtin_nontemporal_load(g + 512 + l);
+}
+__device__ __forceinline__ void hoff_store(double* __restrict__ hoff, int64_t q, const double (&v)[9]) {
+  double* g = hoff + (q >> 6) * 576;
+  const int l = (int)(q & 63);
+  double2* g2 = reinterpret_cast<double2*>(g) + l;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) g2[64 * k] = make_double2(v[2 * k], v[2 * k + 1]);
+  g[512 + l] = v[8];
+}
+// a pose's three doubles of the gathered vector: one 16-byte + one 8-byte load (the vector is 8-byte aligned only)
+typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void gather3(const double* __restrict__ p, int64_t col, double& p0, double& p1, double& p2) {
+  const double* q = p + PS * col;
+  const double2_a8 t = *reinterpret_cast<const double2_a8*>(q);
+  p0 = t.x;
+  p1 = t.y;
+  p2 = q[2];
+}
 
 // ------------------------------------------------- XCD-aware work mapping
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD; speed only, never
@@ -458,14 +510,16 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
             }
           }
         }
+        double HB[9];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
             double v = S[a] * O[b] + S[3 + a] * O[3 + b] + S[6 + a] * O[6 + b];
             if constexpr (SC) v -= cc * vs[a] * vo[b];  // J'(I - c j j')J
-            A.hoff[hoff_index(3 * a + b, q)] = v;
+            HB[3 * a + b] = v;
           }
+        hoff_store(A.hoff, q, HB);
         double d0 = S[0] * S[0] + S[3] * S[3] + S[6] * S[6], d1 = S[0] * S[1] + S[3] * S[4] + S[6] * S[7];
         double d2 = S[0] * S[2] + S[3] * S[5] + S[6] * S[8], d3 = S[1] * S[1] + S[4] * S[4] + S[7] * S[7];
         double d4 = S[1] * S[2] + S[4] * S[5] + S[7] * S[8], d5 = S[2] * S[2] + S[5] * S[5] + S[8] * S[8];
@@ -519,10 +573,12 @@ struct SpmvArgs {
   const int32_t* inc_ptr;
   const int32_t* inc_col;    // global pose position of the column block
   const int32_t* tile_row;
+  const int4* tile_desc;     // per tile {first local row, rows, first incidence, incidences}
   int32_t n_tiles;
   int32_t n_loc;
   int32_t lo;                // first owned global row
   int32_t with_d2;
+  int32_t nt;                // non-temporal loads of the H stream
   int64_t inc_stride;
   const double* hoff;        // AoSoA, see hoff_index
   const double* hd;          // 6 planes
@@ -550,13 +606,27 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   double dot = 0.0;
   int buf = 0;
   const int64_t n = A.n_loc;
-  constexpr int64_t S = 64;  // value stride inside a 64-incidence group (hoff_index)
   const XcdRange xr = xcd_range(A.n_tiles);
-  for (int t = xr.begin; t < xr.end; t += xr.step) {
-    const int r0 = A.tile_row[t], r1 = A.tile_row[t + 1];
-    const int nrows = r1 - r0;
-    const int q0 = A.inc_ptr[r0], q1 = A.inc_ptr[r1];
-    if (q1 - q0 <= WG) {
+  // A tile used to cost four DEPENDENT memory round trips (tile_row -> inc_ptr -> inc_col -> p[col]); with eight
+  // workgroups per CU already resident that chain, not bandwidth, set the pace (structure alone 44 us, + H stream
+  // 150 us, + gather 190 us at 1M poses).  Now the tile's descriptor {first row, rows, first incidence, incidences} is one
+  // 16-byte record, and the NEXT tile's descriptor and column indices are fetched while the current tile is in flight:
+  // per tile one round trip (H stream + gather + row operands, all independent) remains.
+  int t = xr.begin;
+  int4 d = make_int4(0, 0, 0, 0);
+  int col_pf = 0;
+  if (t < xr.end) {
+    d = A.tile_desc[t];
+    if (d.w <= WG && tid < d.w) col_pf = A.inc_col[d.z + tid];
+  }
+  for (; t < xr.end; t += xr.step) {
+    const int r0 = d.x, nrows = d.y, q0 = d.z, nq = d.w;
+    const int q1 = q0 + nq;
+    const int tn = t + xr.step;
+    int4 dn = d;
+    if (tn < xr.end) dn = A.tile_desc[tn];   // oldest load of the iteration: back long before it is needed
+    int col_n = 0;
+    if (nq <= WG) {
       // ---- common case: the tile is one chunk.  Row-phase operands are fetched up front so that
       // their latency overlaps the lane phase instead of following the barrier.
       const bool pv = tid < nrows * 3;
@@ -578,29 +648,32 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         pr2 = pr[2];
       }
       const int q = q0 + tid;
-      if (q < q1) {
-        const int64_t col = A.inc_col[q];
-        double p0, p1, p2;
-        if (MODE == 4 && (col < A.lo || col >= (int64_t)A.lo + A.n_loc)) {
-          scr[buf][0][tid] = 0.0;
-          scr[buf][1][tid] = 0.0;
-          scr[buf][2][tid] = 0.0;
-        } else {
+      const bool lane_on = q < q1;
+      const int64_t col = col_pf;
+      const bool skip = MODE == 4 && (col < A.lo || col >= (int64_t)A.lo + A.n_loc);
+      double p0 = 0.0, p1 = 0.0, p2 = 0.0, h[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (lane_on && !skip) {
         if (MODE == 1 || MODE == 3) {
           p0 = (double)col; p1 = p0 + 1.0; p2 = p0 + 2.0;
         } else {
-          p0 = A.p[PS * col]; p1 = A.p[PS * col + 1]; p2 = A.p[PS * col + 2];
+          gather3(A.p, col, p0, p1, p2);
         }
-        const double* h = A.hoff + hoff_index(0, q);
+        if (MODE != 2 && MODE != 3) {
+          if (A.nt) hoff_load_nt(A.hoff, q, h);
+          else hoff_load(A.hoff, q, h);
+        }
+      }
+      // the next tile's column indices (its descriptor has arrived: it was the first load of this iteration)
+      if (tn < xr.end && dn.w <= WG && tid < dn.w) col_n = A.inc_col[dn.z + tid];
+      if (lane_on) {
         if (MODE == 2 || MODE == 3) {
           scr[buf][0][tid] = p0 + 2.0 * p1 + 3.0 * p2;
           scr[buf][1][tid] = p0 - p1;
           scr[buf][2][tid] = p2 * p1;
         } else {
-          scr[buf][0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
-          scr[buf][1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
-          scr[buf][2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
-        }
+          scr[buf][0][tid] = h[0] * p0 + h[1] * p1 + h[2] * p2;   // skipped (remote-column) blocks: h = 0
+          scr[buf][1][tid] = h[3] * p0 + h[4] * p1 + h[5] * p2;
+          scr[buf][2][tid] = h[6] * p0 + h[7] * p1 + h[8] * p2;
         }
       }
       __syncthreads();
@@ -619,11 +692,11 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         for (int j = lo2; j < hi2; ++j) s += scr[buf][a2][j];
         const double* pr = A.p + PS * (int64_t)(A.lo + row2);
         const int i1 = (a2 == 0) ? 1 : (a2 == 1 ? 3 : 4), i2 = (a2 == 2) ? 5 : (a2 == 1 ? 4 : 2);
-        double d = A.hd[(int64_t)a2 * n + row2] * pr[0];
-        d += A.hd[(int64_t)i1 * n + row2] * pr[1];
-        d += A.hd[(int64_t)i2 * n + row2] * pr[2];
-        if (A.with_d2) d += A.d2[3 * (int64_t)row2 + a2] * pr[a2];
-        s += d;
+        double dg = A.hd[(int64_t)a2 * n + row2] * pr[0];
+        dg += A.hd[(int64_t)i1 * n + row2] * pr[1];
+        dg += A.hd[(int64_t)i2 * n + row2] * pr[2];
+        if (A.with_d2) dg += A.d2[3 * (int64_t)row2 + a2] * pr[a2];
+        s += dg;
         A.y[3 * (int64_t)row2 + a2] = s;
         dot += pr[a2] * s;
       }
@@ -640,11 +713,12 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
             scr[buf][1][tid] = 0.0;
             scr[buf][2][tid] = 0.0;
           } else {
-            const double p0 = A.p[PS * col], p1 = A.p[PS * col + 1], p2 = A.p[PS * col + 2];
-            const double* h = A.hoff + hoff_index(0, q);
-            scr[buf][0][tid] = h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
-            scr[buf][1][tid] = h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
-            scr[buf][2][tid] = h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
+            double p0, p1, p2, h[9];
+            gather3(A.p, col, p0, p1, p2);
+            hoff_load(A.hoff, q, h);
+            scr[buf][0][tid] = h[0] * p0 + h[1] * p1 + h[2] * p2;
+            scr[buf][1][tid] = h[3] * p0 + h[4] * p1 + h[5] * p2;
+            scr[buf][2][tid] = h[6] * p0 + h[7] * p1 + h[8] * p2;
           }
         }
         __syncthreads();
@@ -660,15 +734,18 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         const int a = tid, row = r0;
         const double* pr = A.p + PS * (int64_t)(A.lo + row);
         const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
-        double d = A.hd[(int64_t)a * n + row] * pr[0];
-        d += A.hd[(int64_t)i1 * n + row] * pr[1];
-        d += A.hd[(int64_t)i2 * n + row] * pr[2];
-        if (A.with_d2) d += A.d2[3 * (int64_t)row + a] * pr[a];
-        const double s = acc + d;
+        double dg = A.hd[(int64_t)a * n + row] * pr[0];
+        dg += A.hd[(int64_t)i1 * n + row] * pr[1];
+        dg += A.hd[(int64_t)i2 * n + row] * pr[2];
+        if (A.with_d2) dg += A.d2[3 * (int64_t)row + a] * pr[a];
+        const double s = acc + dg;
         A.y[3 * (int64_t)row + a] = s;
         dot += pr[a] * s;
       }
+      if (tn < xr.end && dn.w <= WG && tid < dn.w) col_n = A.inc_col[dn.z + tid];
     }
+    d = dn;
+    col_pf = col_n;
   }
   const double tot = block_sum_bcast(dot, red);
   if (tid == 0) A.dot_part[blockIdx.x] = tot;
@@ -692,7 +769,6 @@ struct RemoteArgs {
 __global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
   __shared__ double red[8];
   if (A.done && *A.done) return;
-  constexpr int64_t S = 64;
   double dot = 0.0;
   for (int i = blockIdx.x * WG + threadIdx.x; i < A.n_rows; i += gridDim.x * WG) {
     const int row = A.rows[i];
@@ -700,11 +776,12 @@ __global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
     for (int k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
       const int q = A.slots[k];
       const int64_t col = A.inc_col[q];
-      const double p0 = A.p[PS * col], p1 = A.p[PS * col + 1], p2 = A.p[PS * col + 2];
-      const double* h = A.hoff + hoff_index(0, q);
-      s0 += h[0] * p0 + h[S] * p1 + h[2 * S] * p2;
-      s1 += h[3 * S] * p0 + h[4 * S] * p1 + h[5 * S] * p2;
-      s2 += h[6 * S] * p0 + h[7 * S] * p1 + h[8 * S] * p2;
+      double p0, p1, p2, h[9];
+      gather3(A.p, col, p0, p1, p2);
+      hoff_load(A.hoff, q, h);
+      s0 += h[0] * p0 + h[1] * p1 + h[2] * p2;
+      s1 += h[3] * p0 + h[4] * p1 + h[5] * p2;
+      s2 += h[6] * p0 + h[7] * p1 + h[8] * p2;
     }
     double* y = A.y + 3 * (int64_t)row;
     const double* pr = A.p + PS * (int64_t)(A.lo + row);
@@ -1006,10 +1083,11 @@ __global__ __launch_bounds__(WG) void k_prepare_groups(GroupPrepArgs A) {
         const int col = A.inc_col[q] - A.lo;
         if (col >= g0 && col < g1) {
           const int row = upper_row(A.inc_ptr, g0, g1, q);
-          const double* h = A.hoff + hoff_index(0, q);
+          double h[9];
+          hoff_load(A.hoff, q, h);
           for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b)
-              atomicAdd(&M[(3 * (row - g0) + a) * ld + 3 * (col - g0) + b], h[(3 * a + b) * 64]);  // duplicate pairs add up
+              atomicAdd(&M[(3 * (row - g0) + a) * ld + 3 * (col - g0) + b], h[3 * a + b]);  // duplicate pairs add up
         }
       }
     }
@@ -1150,6 +1228,12 @@ __host__ __device__ __forceinline__ int64_t chain_tidx(int64_t i) {
   return (i & ~(int64_t)(CHAIN_TILE - 1)) + ((i & (CHAIN_CHUNK - 1)) << 6) + ((i & (CHAIN_TILE - 1)) / CHAIN_CHUNK);
 }
 
+// the same for tiles of 64 * ch rows, ch consecutive poses per lane (ch = 4: chain_tidx); used by the lean apply below
+__host__ __device__ __forceinline__ int64_t chain_tidx_g(int64_t i, int ch) {
+  const int64_t tile = 64 * (int64_t)ch;
+  return (i / tile) * tile + ((i % ch) << 6) + ((i % tile) / ch);
+}
+
 struct ChainPre {
   const double* cw;   // 9 planes [n_pad]: W_i, row-major 3x3, at chain_tidx(i); 0 at a segment start and in the padding
   const double* cs;   // 6 planes [n_pad]: S_i^-1 (00 01 02 11 12 22), at chain_tidx(i); 0 in the padding
@@ -1188,8 +1272,8 @@ __global__ void k_chain_extract(const int32_t* __restrict__ inc_ptr, const int32
 
 // one thread per segment, sequential along the chain (seg_len dependent 3x3 steps; once per LM iteration); each step
 // reads one 128-byte record
-__global__ void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len, double* __restrict__ cw,
-                               double* __restrict__ cs) {
+__global__ void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len, int chunk,
+                               double* __restrict__ cw, double* __restrict__ cs) {
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = n_loc, np = n_pad;
   const int64_t s0 = (int64_t)seg * seg_len;
@@ -1217,7 +1301,7 @@ __global__ void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_
       a12 -= W[3] * C[6] + W[4] * C[7] + W[5] * C[8];
       a22 -= W[6] * C[6] + W[7] * C[7] + W[8] * C[8];
     }
-    const int64_t ti = chain_tidx(i);
+    const int64_t ti = chain_tidx_g(i, chunk);  // chunk = 4: chain_tidx
 #pragma unroll
     for (int c = 0; c < 9; ++c) cw[(int64_t)c * np + ti] = W[c];
     const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
@@ -1497,6 +1581,320 @@ __global__ __launch_bounds__(WG) void k_cg_update1_c(CgVec V, ChainPre C, int pa
       }
     }
     __syncthreads();
+  }
+  rz = block_sum_bcast(rz, red);
+  rr = block_sum_bcast(rr, red);
+  if (tid == 0) {
+    part_rz[blockIdx.x] = rz;
+    part_rr[blockIdx.x] = rr;
+  }
+}
+
+// ------------------------------------------------- chain preconditioner, lean apply (segments of <= 64 * CH rows)
+// Second form of the same apply, built for occupancy: the scan-based kernel above keeps ~244 VGPRs live (2 waves/SIMD)
+// and couples its four waves with workgroup barriers, so in the PCG loop -- where its 288 B/row arrive from HBM, the
+// SpMV stream having flushed every cache -- it is latency-bound (81 us at 1M poses, 0.44 of the HBM roofline).  Here
+//   * a wavefront owns a tile of 64 * CH rows (CH = 2: 128 rows, 30 doubles of factors per lane instead of 60);
+//   * the chunk maps are NOT scanned as (vector, matrix) pairs: the chunk's matrix F = (-W_{CH-1}) ... (-W_0) depends on
+//     the factors only, so the values at the chunk ends follow from the first-order recurrence x_l = a_l + F_l x_{l-1}
+//     over the lanes, run as (lanes per segment - 1) steps of one DPP wave shift (wave_shr:1 / wave_shl:1, bound_ctrl:
+//     lane 0 / 63 read 0) + 9 FMA -- no matrix temporaries, no LDS-crossbar shuffles.  F_l = 0 on the first lane of a
+//     segment (W = 0 there), so segments do not interact and no masks are needed;
+//   * W stays in registers for both sweeps (the backward sweep needs W_{k+1}: the next lane's W_0 arrives by one DPP
+//     shift), S^-1 is loaded while the forward recurrence runs: ONE batch of factor loads per tile instead of three;
+//   * the four waves of a workgroup never wait for each other inside the tile loop (wave-private LDS tile, wave-scope
+//     fences), so their memory phases drift apart and overlap.
+// Factor planes: same 9 + 6 planes, transposed inside tiles of 64 * CH rows (chain_tidx_g).
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS instructions of one wavefront execute in order; this only stops the compiler from moving them across
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// value of lane - 1 (0 in lane 0) / lane + 1 (0 in lane 63): DPP wavefront shifts, two v_mov_b32_dpp per double
+__device__ __forceinline__ double wave_prev(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_next(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);  // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// In place on the lane's chunk `ch` of the wave-private LDS tile (pose k, component c at 3 k + c): r on entry, z = M^-1 r
+// on exit.  W: this lane's W_k (registers, loaded by the caller).  csl: S^-1 planes at this lane (+ c * np + k * 64).
+// n_steps = lanes per segment - 1.
+template <int CH>
+__device__ __forceinline__ void chain_apply_lean(const double (&W)[CH][9], const double* __restrict__ cs_tile, int64_t np,
+                                                 unsigned lane, double* __restrict__ ch, int n_steps) {
+  // S^-1 (uniform plane base + lane): issued now, consumed after the forward recurrence
+  double S[CH][6];
+#pragma unroll
+  for (int k = 0; k < CH; ++k)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) S[k][c] = (cs_tile + ((int64_t)c * np + k * 64))[lane];
+  // ---- forward, chunk map from a zero input: a = t_{CH-1}, F = (-W_{CH-1}) ... (-W_0)
+  double a[3] = {ch[0], ch[1], ch[2]}, F[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) F[c] = -W[0][c];
+#pragma unroll
+  for (int k = 1; k < CH; ++k) {
+    const double* w = W[k];
+    const double t0 = ch[3 * k] - (w[0] * a[0] + w[1] * a[1] + w[2] * a[2]);
+    const double t1 = ch[3 * k + 1] - (w[3] * a[0] + w[4] * a[1] + w[5] * a[2]);
+    const double t2 = ch[3 * k + 2] - (w[6] * a[0] + w[7] * a[1] + w[8] * a[2]);
+    a[0] = t0; a[1] = t1; a[2] = t2;
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[3 * i + j] = -(w[3 * i] * F[j] + w[3 * i + 1] * F[3 + j] + w[3 * i + 2] * F[6 + j]);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) F[c] = R[c];
+  }
+  // ---- recurrence over the lanes: x_l = a_l + F_l x_{l-1}
+  double x0 = a[0], x1 = a[1], x2 = a[2];
+  for (int s = 0; s < n_steps; ++s) {
+    const double p0 = wave_prev(x0), p1 = wave_prev(x1), p2 = wave_prev(x2);
+    x0 = a[0] + (F[0] * p0 + F[1] * p1 + F[2] * p2);
+    x1 = a[1] + (F[3] * p0 + F[4] * p1 + F[5] * p2);
+    x2 = a[2] + (F[6] * p0 + F[7] * p1 + F[8] * p2);
+  }
+  // ---- forward, true sweep from the end of the previous chunk; u = S^-1 t kept in registers
+  double U[CH][3];
+  {
+    double t0 = wave_prev(x0), t1 = wave_prev(x1), t2 = wave_prev(x2);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const double* w = W[k];
+      const double* q = S[k];
+      const double n0 = ch[3 * k] - (w[0] * t0 + w[1] * t1 + w[2] * t2);
+      const double n1 = ch[3 * k + 1] - (w[3] * t0 + w[4] * t1 + w[5] * t2);
+      const double n2 = ch[3 * k + 2] - (w[6] * t0 + w[7] * t1 + w[8] * t2);
+      t0 = n0; t1 = n1; t2 = n2;
+      U[k][0] = q[0] * t0 + q[1] * t1 + q[2] * t2;
+      U[k][1] = q[1] * t0 + q[3] * t1 + q[4] * t2;
+      U[k][2] = q[2] * t0 + q[4] * t1 + q[5] * t2;
+    }
+  }
+  // ---- backward: z_k = u_k - V_k' z_{k+1},  V_k = W_{k+1}; V_{CH-1} = the next lane's W_0 (0 after lane 63)
+  double VL[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) VL[c] = wave_next(W[0][c]);
+  double b[3] = {U[CH - 1][0], U[CH - 1][1], U[CH - 1][2]}, G[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G[3 * i + j] = -VL[3 * j + i];
+#pragma unroll
+  for (int k = CH - 2; k >= 0; --k) {
+    const double* w = W[k + 1];
+    const double z0 = U[k][0] - (w[0] * b[0] + w[3] * b[1] + w[6] * b[2]);
+    const double z1 = U[k][1] - (w[1] * b[0] + w[4] * b[1] + w[7] * b[2]);
+    const double z2 = U[k][2] - (w[2] * b[0] + w[5] * b[1] + w[8] * b[2]);
+    b[0] = z0; b[1] = z1; b[2] = z2;
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[3 * i + j] = -(w[i] * G[j] + w[3 + i] * G[3 + j] + w[6 + i] * G[6 + j]);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) G[c] = R[c];
+  }
+  double y0 = b[0], y1 = b[1], y2 = b[2];
+  for (int s = 0; s < n_steps; ++s) {
+    const double p0 = wave_next(y0), p1 = wave_next(y1), p2 = wave_next(y2);
+    y0 = b[0] + (G[0] * p0 + G[1] * p1 + G[2] * p2);
+    y1 = b[1] + (G[3] * p0 + G[4] * p1 + G[5] * p2);
+    y2 = b[2] + (G[6] * p0 + G[7] * p1 + G[8] * p2);
+  }
+  {
+    double z0 = wave_next(y0), z1 = wave_next(y1), z2 = wave_next(y2);
+#pragma unroll
+    for (int k = CH - 1; k >= 0; --k) {
+      double VN[9];  // shifted again instead of kept live through the recurrence
+      if (k == CH - 1) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) VN[c] = wave_next(W[0][c]);
+      }
+      const double* w = (k == CH - 1) ? VN : W[(k + 1 < CH) ? k + 1 : 0];
+      const double n0 = U[k][0] - (w[0] * z0 + w[3] * z1 + w[6] * z2);
+      const double n1 = U[k][1] - (w[1] * z0 + w[4] * z1 + w[7] * z2);
+      const double n2 = U[k][2] - (w[2] * z0 + w[5] * z1 + w[8] * z2);
+      z0 = n0; z1 = n1; z2 = n2;
+      ch[3 * k] = z0;
+      ch[3 * k + 1] = z1;
+      ch[3 * k + 2] = z2;
+    }
+  }
+}
+
+// PCG start-up, lean chain apply: r = b, z = M^-1 r, y = 0, p = z; partials of r.z and b.b.  One wavefront per tile of
+// 64 * CH rows, tiles dealt round-robin over all waves of the grid.  FULL tiles (all but possibly the last) run without
+// per-element predicates: every load of the tile is issued before the first use.
+template <int CH>
+__global__ __launch_bounds__(WG) void k_cg_init_cl(CgVec V, ChainPre C, int n_steps, const double* __restrict__ b,
+                                                   double* __restrict__ part_rz, double* __restrict__ part_bb) {
+  constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
+  __shared__ double tile[4][64 * STRIDE];
+  __shared__ double red[8];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  double* buf = tile[wave];
+  double* ch = buf + lane * STRIDE;
+  const int64_t n3 = 3 * (int64_t)V.n_loc, np = C.n_pad;
+  double* __restrict__ vy = V.y;
+  double* __restrict__ vr = V.r;
+  double* __restrict__ vz = V.z;
+  double* __restrict__ vp = V.p + 3 * (int64_t)V.lo;
+  double rz = 0.0, bb = 0.0;
+  const int64_t n_tiles = ((int64_t)V.n_loc + TILE - 1) / TILE;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n_tiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t wbase = t * TILE, f0 = 3 * wbase;   // uniform: plane / vector bases stay scalar, lane offsets 32-bit
+    const unsigned lim = (unsigned)(n3 - f0 < 3 * TILE ? n3 - f0 : 3 * TILE);
+    const double* cw_tile = C.cw + wbase;
+    double W[CH][9];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+      for (int c = 0; c < 9; ++c) W[k][c] = (cw_tile + ((int64_t)c * np + k * 64))[lane];
+    const double* bt = b + f0;
+    double rv[NV];
+    if (lim == 3u * TILE) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) rv[j] = bt[lane + 64u * j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) rv[j] = (lane + 64u * j) < lim ? bt[lane + 64u * j] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const unsigned e = lane + 64u * j;
+      buf[e + e / (3 * CH)] = rv[j];
+    }
+    wave_lds_sync();
+    chain_apply_lean<CH>(W, C.cs + wbase, np, lane, ch, n_steps);
+    wave_lds_sync();
+    double* yt = vy + f0;
+    double* rt = vr + f0;
+    double* zt = vz + f0;
+    double* pt = vp + f0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const unsigned e = lane + 64u * j;
+      const double z = buf[e + e / (3 * CH)], r = rv[j];
+      if (lim == 3u * TILE || e < lim) {
+        yt[e] = 0.0;
+        rt[e] = r;
+        zt[e] = z;
+        pt[e] = z;
+      }
+      rz += r * z;   // rows past the end hold r = z = 0
+      bb += r * r;
+    }
+    wave_lds_sync();
+  }
+  rz = block_sum_bcast(rz, red);
+  bb = block_sum_bcast(bb, red);
+  if (tid == 0) {
+    part_rz[blockIdx.x] = rz;
+    part_bb[blockIdx.x] = bb;
+  }
+}
+
+// x += alpha p ; r -= alpha A p ; z = M^-1 r (lean chain apply) ; partials of r.z and r.r
+template <int CH>
+__global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n_steps, int parity,
+                                                      const double* __restrict__ part_pap, int n_pap,
+                                                      double* __restrict__ part_rz, double* __restrict__ part_rr) {
+  constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
+  __shared__ double tile[4][64 * STRIDE];
+  __shared__ double red[8];
+  if (V.st->done) return;
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const double pap = sum_partials_bcast(part_pap, n_pap, red);
+  const double alpha = V.st->rz[parity] / pap;
+  double* buf = tile[wave];
+  double* ch = buf + lane * STRIDE;
+  const int64_t n3 = 3 * (int64_t)V.n_loc, np = C.n_pad;
+  double* __restrict__ vy = V.y;
+  double* __restrict__ vr = V.r;
+  double* __restrict__ vz = V.z;
+  const double* __restrict__ vap = V.ap;
+  const double* __restrict__ pown = V.p + 3 * (int64_t)V.lo;
+  double rz = 0.0, rr = 0.0;
+  const int64_t n_tiles = ((int64_t)V.n_loc + TILE - 1) / TILE;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n_tiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t wbase = t * TILE, f0 = 3 * wbase;   // uniform: plane / vector bases stay scalar, lane offsets 32-bit
+    const unsigned lim = (unsigned)(n3 - f0 < 3 * TILE ? n3 - f0 : 3 * TILE);
+    const bool full = lim == 3u * TILE;
+    const double* cw_tile = C.cw + wbase;
+    double W[CH][9];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+      for (int c = 0; c < 9; ++c) W[k][c] = (cw_tile + ((int64_t)c * np + k * 64))[lane];
+    double* yt = vy + f0;
+    double* rt = vr + f0;
+    const double* at = vap + f0;
+    const double* pt = pown + f0;
+    double rv[NV], yv[NV];
+    if (full) {
+      double av[NV], pv[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const unsigned e = lane + 64u * j;
+        rv[j] = rt[e];
+        av[j] = at[e];
+        yv[j] = yt[e];
+        pv[j] = pt[e];
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        rv[j] -= alpha * av[j];
+        yv[j] += alpha * pv[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const unsigned e = lane + 64u * j;
+        rt[e] = rv[j];
+        yt[e] = yv[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const unsigned e = lane + 64u * j;
+        double r = 0.0;
+        if (e < lim) {
+          yt[e] += alpha * pt[e];
+          r = rt[e] - alpha * at[e];
+          rt[e] = r;
+        }
+        rv[j] = r;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const unsigned e = lane + 64u * j;
+      rr += rv[j] * rv[j];
+      buf[e + e / (3 * CH)] = rv[j];
+    }
+    wave_lds_sync();
+    chain_apply_lean<CH>(W, C.cs + wbase, np, lane, ch, n_steps);
+    wave_lds_sync();
+    double* zt = vz + f0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const unsigned e = lane + 64u * j;
+      const double z = buf[e + e / (3 * CH)];
+      if (full || e < lim) zt[e] = z;
+      rz += rv[j] * z;
+    }
+    wave_lds_sync();
   }
   rz = block_sum_bcast(rz, red);
   rr = block_sum_bcast(rr, red);

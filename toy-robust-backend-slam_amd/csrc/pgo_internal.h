@@ -80,6 +80,9 @@ int build_shard_structure(int32_t n_poses, int32_t n_edges, const int32_t* ia, c
                           const double* meas, const uint8_t* kind, int method, int world, int rank, int row_align,
                           ShardStructure* out);
 
+// processing order of the row tiles for K3 (structure.cpp): order[k] = tile that takes the k-th turn
+void compute_tile_order(const ShardStructure& S, std::vector<int32_t>* order);
+
 // locality ordering (structure.cpp): perm[i] = new position of pose i
 int compute_pose_order(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int32_t segment,
                        std::vector<int32_t>* perm);

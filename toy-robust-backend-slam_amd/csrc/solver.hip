@@ -80,6 +80,7 @@ struct pgo_handle {
   double* chi2_buf = nullptr;  // [n_edges_total], allocated at the first pgo_edge_chi2
   int64_t n_edges_total = 0;
   int32_t *inc_ptr = nullptr, *inc_edge = nullptr, *inc_col = nullptr, *tile_row = nullptr;
+  int4* tile_desc = nullptr;
   int64_t inc_stride = 0;
   // normal equations
   double *hoff = nullptr, *hd = nullptr, *gs = nullptr, *d2 = nullptr, *minv = nullptr;
@@ -100,6 +101,7 @@ struct pgo_handle {
   double* ginv = nullptr;
   // chain (block-tridiagonal) preconditioner over 64-pose segments (opt.pcg_chain_len): C planes, W planes, S^-1 planes
   int chain_len = 0, g_chain = 1, chain_pad = 0;
+  int chain_chunk = 0, chain_steps = 0;  // lean apply: poses per lane (2 / 4) and recurrence steps; 0 = scan kernel (layout chunk 4)
   double *chain_c = nullptr, *chain_w = nullptr, *chain_s = nullptr;
   // halo exchange of the search direction (world > 1, opt.halo_exchange)
   bool use_halo = false;
@@ -161,6 +163,7 @@ struct pgo_handle {
   // exercise the RCCL calls themselves: at world == 1 they are identities)
   bool force_collectives = false;
   int spmv_ablate = 0;  // timing-only ablations of k_spmv, set by pgo_bench_spmv from PGO_SPMV_ABLATE
+  int spmv_nt = 1;      // non-temporal H-stream loads in k_spmv (PGO_SPMV_NT=0 turns them off): 179 -> 166 us at 1M poses
   bool multi_rank() const { return comm && (comm->world > 1 || force_collectives); }
 
   template <class T>
@@ -330,10 +333,12 @@ struct pgo_handle {
     A.inc_ptr = inc_ptr;
     A.inc_col = inc_col;
     A.tile_row = tile_row;
+    A.tile_desc = tile_desc;
     A.n_tiles = S.n_tiles();
     A.n_loc = S.n_loc;
     A.lo = S.lo;
     A.with_d2 = with_d2;
+    A.nt = spmv_nt;
     A.inc_stride = inc_stride;
     A.hoff = hoff;
     A.hd = hd;
@@ -421,6 +426,30 @@ struct pgo_handle {
     return V;
   }
 
+  dev::ChainPre chain_pre() const {
+    dev::ChainPre CP;
+    CP.cw = chain_w;
+    CP.cs = chain_s;
+    CP.n_loc = S.n_loc;
+    CP.n_pad = chain_pad;
+    return CP;
+  }
+  // PCG start-up / first update kernel with the chain preconditioner (scan or lean form)
+  void launch_cg_init_chain(const double* b, double* part_rz, double* part_bb) {
+    const dev::CgVec V = cg_vec();
+    const dev::ChainPre CP = chain_pre();
+    if (chain_chunk == 2) hipLaunchKernelGGL(dev::k_cg_init_cl<2>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, chain_steps, b, part_rz, part_bb);
+    else if (chain_chunk == 4) hipLaunchKernelGGL(dev::k_cg_init_cl<4>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, chain_steps, b, part_rz, part_bb);
+    else hipLaunchKernelGGL(dev::k_cg_init_c, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, b, part_rz, part_bb);
+  }
+  void launch_cg_update1_chain(int par, const double* pap, int n_pap, double* part_rz, double* part_rr) {
+    const dev::CgVec V = cg_vec();
+    const dev::ChainPre CP = chain_pre();
+    if (chain_chunk == 2) hipLaunchKernelGGL(dev::k_cg_update1_cl<2>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, chain_steps, par, pap, n_pap, part_rz, part_rr);
+    else if (chain_chunk == 4) hipLaunchKernelGGL(dev::k_cg_update1_cl<4>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, chain_steps, par, pap, n_pap, part_rz, part_rr);
+    else hipLaunchKernelGGL(dev::k_cg_update1_c, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, par, pap, n_pap, part_rz, part_rr);
+  }
+
   int create(int32_t N, const double* poses_h, int32_t E, const int32_t* ia, const int32_t* ib, const double* meas,
              const double* info6, const uint8_t* kind);
   int linearize(bool reuse_records, bool assemble = true);
@@ -457,6 +486,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   }
   const char* fc = getenv("PGO_FORCE_COLLECTIVES");
   force_collectives = fc && fc[0] == '1';
+  if (const char* nt = getenv("PGO_SPMV_NT")) spmv_nt = atoi(nt);
   grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
   chain_len = pgo::resolve_chain_len(opt.pcg_chain_len, opt.pcg_block_poses, N, E, ia, ib);
   if (chain_len != 0 && (chain_len < dev::CHAIN_CHUNK || chain_len % dev::CHAIN_CHUNK != 0 || dev::CHAIN_TILE % chain_len != 0))
@@ -560,6 +590,21 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(upload(inc_edge, S.inc_edge));
   PGOC(upload(inc_col, S.inc_col));
   PGOC(upload(tile_row, S.tile_row));
+  {  // one 16-byte descriptor per tile for K3: {first local row, rows, first incidence, incidences}
+    // in breadth-first order of the tile graph (compute_tile_order): tiles running together gather the same lines
+    std::vector<int4> desc((size_t)std::max(1, S.n_tiles()));
+    std::vector<int32_t> order;
+    const char* to = getenv("PGO_TILE_ORDER");
+    if (!(to && to[0] == '0') && S.n_tiles() >= 4096) pgo::compute_tile_order(S, &order);
+    for (int k = 0; k < S.n_tiles(); ++k) {
+      const int t = order.empty() ? k : order[k];
+      const int32_t r0 = S.tile_row[t], r1 = S.tile_row[t + 1];
+      desc[k] = make_int4(r0, r1 - r0, S.inc_ptr[r0], S.inc_ptr[r1] - S.inc_ptr[r0]);
+    }
+    PGOC(dalloc(&tile_desc, (int64_t)desc.size()));
+    PGOC(upload(tile_desc, desc));
+    PGOC(sync());  // `desc` dies with this scope
+  }
   if (has_sw) {  // switches start at 1.0 (main.cpp:117,139)
     std::vector<double> ones((size_t)EL, 1.0);
     PGOC(upload(sw, ones));
@@ -634,6 +679,19 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     HIPC(hipMemsetAsync(chain_w, 0, (size_t)9 * chain_pad * sizeof(double), stream));
     HIPC(hipMemsetAsync(chain_s, 0, (size_t)6 * chain_pad * sizeof(double), stream));
     g_chain = (int)std::min<int64_t>((NL + 4 * dev::CHAIN_TILE - 1) / (4 * dev::CHAIN_TILE), 2048);
+    // apply kernel: the lean form (one DPP-shift recurrence step per lane of a segment) for segments of <= 64 poses, the
+    // log-depth scan form for longer ones; PGO_CHAIN_KERNEL = scan | lean2 | lean4 overrides (experiments)
+    chain_chunk = chain_len <= 64 ? 2 : 0;
+    if (const char* ck = getenv("PGO_CHAIN_KERNEL")) {
+      if (!strcmp(ck, "scan")) chain_chunk = 0;
+      else if (!strcmp(ck, "lean2") && (128 % chain_len) == 0) chain_chunk = 2;
+      else if (!strcmp(ck, "lean4")) chain_chunk = 4;
+    }
+    if (chain_chunk) {
+      chain_steps = chain_len / chain_chunk - 1;
+      const int64_t n_wt = (NL + 64 * chain_chunk - 1) / (64 * chain_chunk);
+      g_chain = (int)std::min<int64_t>((n_wt + 3) / 4, 2048);
+    }
   } else {
     chain_len = 0;
   }
@@ -764,13 +822,8 @@ int pgo_handle::pcg(int* iters, double* rel) {
   GP.nb_pad = grp_pad;
   GP.n_groups = n_groups;
   const bool grouped = grp_B > 1, chained = chain_len > 0;
-  dev::ChainPre CP;
-  CP.cw = chain_w;
-  CP.cs = chain_s;
-  CP.n_loc = S.n_loc;
-  CP.n_pad = chain_pad;
   const int g_u1 = chained ? g_chain : (grouped ? g_grp : g_vec);  // grid (= number of partials) of the init / update1 kernels
-  if (chained) hipLaunchKernelGGL(dev::k_cg_init_c, dim3(g_u1), dim3(dev::WG), 0, stream, V, CP, (const double*)gs, part[0], part[1]);
+  if (chained) launch_cg_init_chain(gs, part[0], part[1]);
   else if (grouped) hipLaunchKernelGGL(dev::k_cg_init_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, (const double*)gs, part[0], part[1]);
   else hipLaunchKernelGGL(dev::k_cg_init, dim3(g_u1), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
   PGOC(check_launch("k_cg_init"));
@@ -788,7 +841,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
     const double* pap = multi ? scal + 6 : part[0];
     const int n_pap = multi ? 1 : n_sp;
     if (multi) PGOC(reduce_to_scal({{part[0], n_sp, 0}}, 6));
-    if (chained) hipLaunchKernelGGL(dev::k_cg_update1_c, dim3(g_u1), dim3(dev::WG), 0, stream, V, CP, par, pap, n_pap, part[1], part[2]);
+    if (chained) launch_cg_update1_chain(par, pap, n_pap, part[1], part[2]);
     else if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, par, pap, n_pap, part[1], part[2]);
     else hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_u1), dim3(dev::WG), 0, stream, V, par, pap, n_pap, part[1], part[2]);
     PGOC(check_launch("k_cg_update1"));
@@ -896,7 +949,7 @@ int pgo_handle::lm_iteration(bool* stop) {
     PGOC(check_launch("k_chain_extract"));
     const int n_seg = (S.n_loc + chain_len - 1) / chain_len;
     hipLaunchKernelGGL(dev::k_chain_factor, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc,
-                       chain_pad, chain_len, chain_w, chain_s);
+                       chain_pad, chain_len, chain_chunk ? chain_chunk : dev::CHAIN_CHUNK, chain_w, chain_s);
     PGOC(check_launch("k_chain_factor"));
   }
   int k_it = 0;
@@ -1427,12 +1480,7 @@ int pgo_debug_precond(pgo_t* h, const double* r_in, double* z_out) {
   HIPC(hipMemcpyAsync(h->ap, src, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));  // ap: scratch input
   dev::CgVec V = h->cg_vec();
   if (h->chain_len) {
-    dev::ChainPre CP;
-    CP.cw = h->chain_w;
-    CP.cs = h->chain_s;
-    CP.n_loc = h->S.n_loc;
-    CP.n_pad = h->chain_pad;
-    hipLaunchKernelGGL(dev::k_cg_init_c, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->ap, h->part[0], h->part[1]);
+    h->launch_cg_init_chain(h->ap, h->part[0], h->part[1]);
   } else if (h->grp_B > 1) {
     dev::GroupPre GP;
     GP.ginv = h->ginv;
@@ -1523,14 +1571,7 @@ int pgo_bench_precond(pgo_t* h, int reps, pgo_kernel_stats* out) {
   double ms = 0;
   const double nl = (double)h->S.n_loc;
   if (h->chain_len) {
-    dev::ChainPre CP;
-    CP.cw = h->chain_w;
-    CP.cs = h->chain_s;
-    CP.n_loc = h->S.n_loc;
-    CP.n_pad = h->chain_pad;
-    PGOC(time_launches(h, reps, [&] {
-      hipLaunchKernelGGL(dev::k_cg_init_c, dim3(h->g_chain), dim3(dev::WG), 0, h->stream, V, CP, (const double*)h->gs, h->part[0], h->part[1]);
-    }, &ms));
+    PGOC(time_launches(h, reps, [&] { h->launch_cg_init_chain(h->gs, h->part[0], h->part[1]); }, &ms));
     out->algorithmic_bytes = (120.0 + 24.0 + 4 * 24.0) * nl;   // W, S^-1 planes + b read; y, r, z, p written
   } else if (h->grp_B > 1) {
     dev::GroupPre GP;

@@ -258,6 +258,62 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
   return PGO_OK;
 }
 
+// Processing order of the row tiles for the SpMV (K3): breadth-first over the tile graph, so that tiles that run at
+// the same time on one XCD (xcd_range deals each XCD one contiguous eighth of the order) gather the same lines of the
+// search direction from that XCD's L2.  Memory layout, row order and every sum are untouched: a tile writes its own
+// rows whatever its turn.  Tile graph: tile +- 1 (the odometry chain) and every SUPPORTED loop edge -- an edge (a, b)
+// counts only if some other edge joins a' in {a-1, a, a+1} with b' in {b-1, b, b+1}; real revisits come in such
+// runs, isolated false loops (the reference's add_random_C draws uniform pairs, g2o_util.h:151-171) do not, and they
+// would turn the graph into a small world without any locality.
+void compute_tile_order(const ShardStructure& S, std::vector<int32_t>* order) {
+  const int32_t nt = S.n_tiles();
+  order->clear();
+  if (nt <= 0) return;
+  order->reserve(nt);
+  std::vector<int32_t> tile_of((size_t)S.n_loc);
+  for (int32_t t = 0; t < nt; ++t)
+    for (int32_t r = S.tile_row[t]; r < S.tile_row[t + 1]; ++r) tile_of[r] = t;
+  const int32_t lo = S.lo, hi = S.hi;
+  auto has_near = [&](int32_t row, int32_t col, int32_t skip_col) {  // row is local; any incidence with column in col +- 1?
+    if (row < 0 || row >= S.n_loc) return false;
+    for (int32_t q = S.inc_ptr[row]; q < S.inc_ptr[row + 1]; ++q) {
+      const int32_t c = S.inc_col[q];
+      if (c >= col - 1 && c <= col + 1 && c != skip_col) return true;
+    }
+    return false;
+  };
+  std::vector<char> seen(nt, 0);
+  std::vector<int32_t> stamp(nt, -1);
+  size_t head = 0;
+  for (int32_t start = 0; start < nt; ++start) {
+    if (seen[start]) continue;
+    seen[start] = 1;
+    order->push_back(start);
+    while (head < order->size()) {
+      const int32_t t = (*order)[head++];
+      auto visit = [&](int32_t u) {
+        if (u >= 0 && u < nt && !seen[u]) {
+          seen[u] = 1;
+          order->push_back(u);
+        }
+      };
+      visit(t - 1);
+      visit(t + 1);
+      for (int32_t r = S.tile_row[t]; r < S.tile_row[t + 1]; ++r)
+        for (int32_t q = S.inc_ptr[r]; q < S.inc_ptr[r + 1]; ++q) {
+          const int32_t c = S.inc_col[q];
+          if (c < lo || c >= hi) continue;
+          const int32_t u = tile_of[c - lo];
+          if (u == t || seen[u] || stamp[u] == t) continue;
+          // supported by a parallel edge?  (r-1 | r | r+1) x (c-1 | c | c+1), not the edge itself
+          const bool ok = has_near(r - 1, c, -1) || has_near(r + 1, c, -1) || has_near(r, c, c);
+          if (ok) visit(u);
+          else stamp[u] = t;  // do not test the same unsupported pair of tiles again for this tile
+        }
+    }
+  }
+}
+
 }  // namespace pgo
 
 extern "C" int pgo_shard_plan(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int world,
