@@ -151,9 +151,9 @@ typedef struct pgo_options {
                                   0 = auto (32 for graphs of <= 8192 poses, which are launch-latency bound and
                                   chain-like, else 4) */
   int32_t halo_exchange;       /* world > 1: how the search direction reaches the other ranks each PCG iteration.
-                                  0 (default) = in-place all-gather of all 3N doubles;
-                                  1 = point-to-point halo exchange: every rank sends each peer only the rows that
-                                      peer's off-diagonal blocks reference (ncclSend/ncclRecv group)            */
+                                  1 (default) = point-to-point halo exchange: every rank sends each peer only the rows that
+                                      peer's off-diagonal blocks reference (one ncclSend/ncclRecv group on the solver's stream);
+                                  0 = in-place all-gather of all 3N doubles                                       */
   double  sc_prior_lambda;     /* 1.0  METHOD 2: weight of the switch prior sqrt(lambda)(1 - s)  (main.cpp:107)    */
   int32_t pose_ordering;       /* internal numbering of the poses (results are always in the caller's numbering):
                                   0 = the caller's, 1 = locality ordering (pgo_pose_order: segments of 64 consecutive
@@ -174,9 +174,11 @@ typedef struct pgo_options {
                                   turns it on and overrides pcg_block_poses; 0 = off;
                                   -1 (default), with pcg_block_poses = 0 (auto): 64 on graphs of > 50000 poses; 256 on chain-like
                                   graphs of 512..8192 poses (few short-range non-consecutive edges); else off                 */
-  int32_t halo_overlap;        /* 1 (default): with halo_exchange = 1, the exchange runs on a second stream while the SpMV
-                                  multiplies the tiles that reference owned columns only; the tiles that need halo rows
-                                  follow.  0: exchange, then one SpMV launch                                            */
+  int32_t halo_overlap;        /* 0 (default): exchange, then one SpMV launch, all on the solver's stream.
+                                  1 (opt-in): with halo_exchange = 1, the exchange runs on a second stream while the SpMV
+                                  multiplies the blocks whose columns are owned; the blocks that need halo rows follow.
+                                  Checked against the plain schedule with the host-staged test communicator only: the
+                                  RCCL send/recv group has not yet run against a real peer                              */
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */
@@ -282,6 +284,26 @@ int pgo_lm_begin(pgo_t* h);                                                     
 int pgo_lm_step(pgo_t* h, int32_t n_iters, int32_t* done, pgo_summary* s);        /* [gpu] */
 int32_t pgo_num_iter_records(const pgo_t* h);
 int pgo_get_iter_records(const pgo_t* h, pgo_iter_record* out, int32_t cap);
+
+/* What the handle resolved its "auto" options to and the size of its shard (bench.py / reports read this instead of
+ * repeating the library's rules).                                                                                   */
+typedef struct pgo_handle_info {
+  int32_t n_poses, n_edges;          /* the whole graph                                                             */
+  int32_t world, rank;
+  int32_t row_lo, row_hi;            /* owned rows, internal numbering                                              */
+  int32_t n_edges_local;             /* edges touching an owned row                                                 */
+  int32_t n_tiles;                   /* row tiles of K2 / K3                                                        */
+  int64_t n_incidences;              /* off-diagonal blocks of the owned rows                                       */
+  int32_t pcg_block_poses;           /* resolved: poses per dense preconditioner block (1 when the chain form is on) */
+  int32_t pcg_chain_len;             /* resolved: segment length of the chain preconditioner, 0 = off               */
+  int32_t chain_kernel;              /* 0 = scan form, 2 / 4 = lean form with that many poses per lane              */
+  int32_t pose_ordering;             /* resolved: 1 = internal locality ordering in use                             */
+  int32_t halo_exchange;             /* resolved: 1 = point-to-point halo exchange, 0 = all-gather / single rank    */
+  int32_t halo_overlap;              /* resolved                                                                    */
+  int64_t halo_send_rows, halo_recv_rows;
+  int64_t device_bytes;              /* HBM allocated by the handle                                                 */
+} pgo_handle_info;
+int pgo_get_info(const pgo_t* h, pgo_handle_info* out);                           /* [host] */
 
 int pgo_get_poses(pgo_t* h, double* out_xyt /* N x 3 */);                         /* [gpu] */
 /* METHOD 2: current switch per edge in the caller's edge order (1.0 for odometry edges); optionally also

@@ -52,6 +52,8 @@ def info_cases():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "info":
         return info_cases()
+    if len(sys.argv) > 1 and sys.argv[1] == "lm":   # only the listed LM cases: make_golden.py lm M3500_out184_m1 ...
+        return lm_cases()
     info_cases()
     # per-edge residual / Jacobian vectors for 20 INTEL edges, both functors
     g = O.read_g2o(os.path.join(DATA, "INTEL.g2o"))
@@ -87,10 +89,19 @@ def main():
                               cost_method1=O.evaluate(g2, method=1, want_r=False, want_J=False)[0])
     json.dump(bog, open(os.path.join(OUT, "intel_bogus.json"), "w"), indent=1)
 
+    lm_cases()
+
+
+def lm_cases():
     # LM traces + final poses (direct solve) for the BASELINE configs C1..C3
-    cases = [("INTEL", 50, 1), ("INTEL", 50, 0), ("INTEL", 0, 1), ("MIT", 0, 1), ("MIT", 0, 0), ("M3500", 0, 1),
+    cases = [("INTEL", 50, 1), ("INTEL", 50, 0), ("INTEL", 0, 1), ("INTEL", 0, 0), ("MIT", 0, 1), ("MIT", 0, 0), ("M3500", 0, 1),
              ("M3500", 0, 0), ("CSAIL", 0, 1), ("FR079", 0, 1), ("FRH", 0, 1), ("FRH", 20, 1)]
+    # "0 and 10 %-of-closures bogus edges, METHOD 0 and 1" on M3500 (1844 closures) and MIT (20 closures)
+    cases += [("M3500", 184, 1), ("M3500", 184, 0), ("MIT", 2, 1), ("MIT", 2, 0)]
+    only = set(sys.argv[2:]) if len(sys.argv) > 2 and sys.argv[1] == "lm" else None
     for name, n_out, method in cases:
+        if only is not None and "%s_out%d_m%d" % (name, n_out, method) not in only:
+            continue
         gg = O.read_g2o(os.path.join(DATA, name + ".g2o"))
         if n_out:
             gg = O.add_random_C(gg, n_out, 1)
@@ -102,6 +113,8 @@ def main():
                        records=res.records), open(os.path.join(OUT, "lm_%s.json" % tag), "w"), indent=1)
         print(tag, O.TERM[res.termination], res.iterations, res.final_cost)
 
+    if only is not None:
+        return
     # METHOD 2 (switchable constraints): joint LM over poses and switches
     for name, n_out in [("INTEL", 50), ("M3500", 0), ("MIT", 0)]:
         gg = O.read_g2o(os.path.join(DATA, name + ".g2o"))

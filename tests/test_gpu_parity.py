@@ -196,8 +196,10 @@ def test_heavy_row_duplicates_isolated(pgo, oracle, n_leaves):
 
 
 # ----------------------------------------------------------------- LM solve
-CASES = [("INTEL", 50, 1), ("INTEL", 50, 0), ("INTEL", 0, 1), ("MIT", 0, 1), ("MIT", 0, 0), ("M3500", 0, 1),
-         ("M3500", 0, 0), ("CSAIL", 0, 1), ("FR079", 0, 1), ("FRH", 0, 1), ("FRH", 20, 1)]
+CASES = [("INTEL", 50, 1), ("INTEL", 50, 0), ("INTEL", 0, 1), ("INTEL", 0, 0), ("MIT", 0, 1), ("MIT", 0, 0), ("M3500", 0, 1),
+         ("M3500", 0, 0), ("CSAIL", 0, 1), ("FR079", 0, 1), ("FRH", 0, 1), ("FRH", 20, 1),
+         # 10 %-of-closures bogus edges (M3500: 184 of 1844, MIT: 2 of 20), METHOD 0 and 1
+         ("M3500", 184, 1), ("M3500", 184, 0), ("MIT", 2, 1), ("MIT", 2, 0)]
 
 
 @pytest.mark.parametrize("name,n_out,method", CASES)
@@ -228,6 +230,53 @@ def test_lm_solve_matches_golden(pgo, name, n_out, method):
     # in-place semantics of the reference (Node::p)
     s.write_back()
     np.testing.assert_array_equal(g.poses, x)
+    s.close()
+
+
+def test_dcs_survives_outliers_plain_collapses(pgo):
+    """The one behavioural result the reference publishes (README.md:38-44, docs/report.png): on INTEL with 50 injected
+    outlier loops the trajectory survives with DCS ON and collapses with DCS OFF.  Asserted on the HIP path (50 LM
+    iterations, the reference's defaults), as the deviation of the translations from the solve of the clean graph with
+    the same METHOD; the oracle's direct-solve fixtures show 0.087 m (DCS) against 23 m (plain)."""
+    dev = {}
+    for method in (1, 0):
+        x = {}
+        for n_out in (0, 50):
+            s = pgo.Solver(load(pgo, "INTEL", n_out), pgo.Options(method=method))
+            s.solve()
+            x[n_out] = s.poses()
+            s.close()
+            ref = np.load(os.path.join(GOLDEN, "lm_INTEL_out%d_m%d_poses.npy" % (n_out, method)))
+            assert np.abs(x[n_out][:, :2] - ref[:, :2]).max() < 1e-4   # and each solve is the oracle's
+        dev[method] = float(np.abs(x[50][:, :2] - x[0][:, :2]).max())
+    print("INTEL + 50 outlier loops, max translation deviation from the clean solve: DCS %.3f m, plain %.1f m" % (dev[1], dev[0]))
+    assert dev[1] < 0.15      # DCS on: still the same map
+    assert dev[0] > 5.0       # DCS off: metres away
+    assert dev[0] > 50 * dev[1]
+
+
+def test_bench_workload_matches_port_at_1m(pgo, oracle):
+    """BASELINE configs[4], the workload bench.py times (1M poses / 4.0M edges, inexact PCG rtol 0.1 <= 500, auto = 64-pose
+    chain preconditioner): the first LM iterations on the GPU against the identical algorithm in the C port -- same
+    accept/reject history, costs to 1e-9, PCG iteration counts within 1, poses to 1e-7."""
+    g = pgo.synth_manhattan(1000000, 4.0, 0.10, 20260410)
+    og = oracle_graph(oracle, g)
+    kw = dict(method=1, max_iters=3, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0, pcg_rtol=0.1, pcg_max_iters=500)
+    s = pgo.Solver(g, pgo.Options(pcg_check_every=10, **kw))
+    inf = s.info()
+    assert inf.pcg_chain_len == 64 and inf.n_poses == 1000000
+    summ = s.solve()
+    ores = oracle.lm_pcg(og, oracle.Options(threads=min(16, os.cpu_count() or 1), pcg_chain_len=inf.pcg_chain_len,
+                                            pcg_block_poses=inf.pcg_block_poses, **kw))
+    recs = s.iter_records()
+    assert len(recs) == len(ores.records) == 4
+    for a, b in zip(recs, ores.records):
+        assert a["step_ok"] == b["step_ok"]
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-9)
+        assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 1
+    d = np.abs(s.poses() - ores.poses).max()
+    print(f"1M poses, 3 LM iterations: GPU {summ.seconds_total:.2f} s, PCG iterations {summ.total_pcg_iters} vs port {ores.total_pcg_iters}, max |d pose| {d:.2e}")
+    assert d < 1e-7
     s.close()
 
 

@@ -123,7 +123,7 @@ def test_sharded_info_weighting_and_chi2(tmp_path, world, halo):
 
 @pytest.mark.parametrize("world,chain", [(2, 64), (4, 0)])
 def test_halo_overlap_matches_plain_exchange(tmp_path, world, chain):
-    """halo_overlap = 1 (default): the blocks with owned columns are multiplied (k_spmv MODE 4) while the exchange runs on
+    """halo_overlap = 1 (opt-in): the blocks with owned columns are multiplied (k_spmv MODE 4) while the exchange runs on
     a second stream, the blocks with remote columns afterwards (k_spmv_remote); 0: exchange, then one SpMV launch.
     Same LM history either way; also against the 1-rank solve."""
     base = dict(graph="synth", n_poses=30001, seed=5,

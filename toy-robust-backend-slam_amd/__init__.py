@@ -21,7 +21,7 @@ import numpy as np
 from . import _build
 
 __all__ = ["PgoError", "Options", "Summary", "IterRecord", "ReadG2O", "Graph", "Solver", "Comm", "lib", "build",
-           "synth_manhattan", "solve_batch", "shard_plan", "shard_halo", "pose_order", "KernelStats", "EXPORTS", "TERMINATION"]
+           "HandleInfo", "synth_manhattan", "solve_batch", "shard_plan", "shard_halo", "pose_order", "KernelStats", "EXPORTS", "TERMINATION"]
 
 EDGE_ODOMETRY, EDGE_CLOSURE, EDGE_BOGUS = 0, 1, 2
 TERMINATION = {1: "CONVERGENCE_FTOL", 2: "CONVERGENCE_GTOL", 3: "CONVERGENCE_PTOL", 4: "NO_CONVERGENCE",
@@ -37,7 +37,7 @@ EXPORTS = [
     "pgo_synth_manhattan", "pgo_options_default",
     "pgo_comm_unique_id", "pgo_comm_create_rccl", "pgo_comm_create_shm", "pgo_comm_destroy",
     "pgo_create", "pgo_create_weighted", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_edge_chi2", "pgo_solve", "pgo_solve_batch", "pgo_lm_begin", "pgo_lm_step",
-    "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
+    "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_info", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
     "pgo_write_switches",
     "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_bench_precond", "pgo_debug_precond", "pgo_debug_spmv", "pgo_debug_normal_eq",
     "pgo_shard_plan", "pgo_shard_halo", "pgo_pose_order",
@@ -93,6 +93,19 @@ class Summary(C.Structure):
         return d
 
 
+class HandleInfo(C.Structure):
+    """mirror of pgo_handle_info"""
+    _fields_ = [("n_poses", C.c_int32), ("n_edges", C.c_int32), ("world", C.c_int32), ("rank", C.c_int32),
+                ("row_lo", C.c_int32), ("row_hi", C.c_int32), ("n_edges_local", C.c_int32), ("n_tiles", C.c_int32),
+                ("n_incidences", C.c_int64), ("pcg_block_poses", C.c_int32), ("pcg_chain_len", C.c_int32),
+                ("chain_kernel", C.c_int32), ("pose_ordering", C.c_int32), ("halo_exchange", C.c_int32),
+                ("halo_overlap", C.c_int32), ("halo_send_rows", C.c_int64), ("halo_recv_rows", C.c_int64),
+                ("device_bytes", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class KernelStats(C.Structure):
     _fields_ = [("ms_avg", C.c_double), ("algorithmic_bytes", C.c_double), ("units", C.c_int64)]
 
@@ -109,13 +122,17 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB
-    if _build.needs_build():
+    path = os.environ.get("PGO_LIB") or _build.LIB   # PGO_LIB: an experiment build (scripts/exp_*.sh), never the default
+    if path == _build.LIB and _build.needs_build():
         try:
             path = _build.build_lib()
-        except Exception as e:  # stale-but-present library is still usable on a box without hipcc
+        except RuntimeError as e:  # no hipcc on this box: a present library is still usable, but say that it is stale
             if not os.path.exists(path):
                 raise ImportError(f"libpgo.so is missing and could not be built: {e}") from e
+            import warnings
+            warnings.warn(f"{path} is OLDER than its sources and hipcc is not available to rebuild it ({e}); "
+                          "running the stale library", RuntimeWarning)
+        # a compile error (CalledProcessError) propagates: never fall back to a stale binary after a failed build
     L = C.CDLL(path)
     vp, dp, ip, bp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
     L.pgo_strerror.restype = C.c_char_p
@@ -163,6 +180,7 @@ def lib():
     L.pgo_num_iter_records.argtypes = [vp]
     L.pgo_num_iter_records.restype = C.c_int32
     L.pgo_get_iter_records.argtypes = [vp, C.POINTER(IterRecord), C.c_int32]
+    L.pgo_get_info.argtypes = [vp, C.POINTER(HandleInfo)]
     L.pgo_get_poses.argtypes = [vp, dp]
     L.pgo_set_poses.argtypes = [vp, dp]
     L.pgo_get_switches.argtypes = [vp, dp, dp]
@@ -451,6 +469,12 @@ class Solver:
         arr = (IterRecord * max(n, 1))()
         _check(lib().pgo_get_iter_records(self._h, arr, n))
         return [arr[i].as_dict() for i in range(n)]
+
+    def info(self) -> HandleInfo:
+        """what the handle resolved its auto options to (pgo_get_info)"""
+        out = HandleInfo()
+        _check(lib().pgo_get_info(self._h, C.byref(out)))
+        return out
 
     def poses(self):
         out = np.zeros((self.n_poses, 3))

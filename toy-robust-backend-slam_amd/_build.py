@@ -29,18 +29,19 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build_lib(force: bool = False, verbose: bool = False, defines=(), out: str = LIB) -> str:
+    """`defines` / `out`: experiment builds (scripts/exp_*.sh) next to the product library, selected with PGO_LIB"""
+    if not force and not needs_build() and out == LIB:
         return LIB
     cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB + ".tmp", "-lrccl", "-pthread"]
+    cmd += ["-o", out + ".tmp", "-lrccl", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
 
 
 def build_cli(force: bool = False) -> str:

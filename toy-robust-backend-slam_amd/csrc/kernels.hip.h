@@ -38,6 +38,29 @@ template <bool INFO> struct RecLayout {
 constexpr int PS = 3;            // doubles per pose in the GATHERED vector p.  Padding to 4 (32 B, never straddling a
                                  // 64-byte sector) was measured: no fewer fetched bytes (FETCH_SIZE 566 vs 557 MiB), so 3.
 
+// ------------------------------------------------- streaming accesses
+// Data that a kernel touches exactly once (matrix / factor streams, CG vectors) is moved with the non-temporal hint so
+// that it does not displace what IS re-used (the gathered search direction) from the XCD's L2.
+#ifndef PGO_NT_STREAMS
+#define PGO_NT_STREAMS 1
+#endif
+template <class T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+#if PGO_NT_STREAMS
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+#if PGO_NT_STREAMS
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // ------------------------------------------------- layout of the off-diagonal blocks
 // AoSoA: incidences in groups of 64 (one wave), 9 values x 64 lanes contiguous (4608 B per group), so
 // that a wave's 9 coalesced 512-byte accesses fall into ONE contiguous 4.5 KiB region instead of nine
@@ -617,7 +640,7 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   int col_pf = 0;
   if (t < xr.end) {
     d = A.tile_desc[t];
-    if (d.w <= WG && tid < d.w) col_pf = A.inc_col[d.z + tid];
+    if (d.w <= WG && tid < d.w) col_pf = ld_stream(A.inc_col + d.z + tid);
   }
   for (; t < xr.end; t += xr.step) {
     const int r0 = d.x, nrows = d.y, q0 = d.z, nq = d.w;
@@ -638,10 +661,10 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         lo = A.inc_ptr[row] - q0;
         hi = A.inc_ptr[row + 1] - q0;
         const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
-        h0 = A.hd[(int64_t)a * n + row];
-        h1 = A.hd[(int64_t)i1 * n + row];
-        h2 = A.hd[(int64_t)i2 * n + row];
-        if (A.with_d2) dd = A.d2[3 * (int64_t)row + a];
+        h0 = ld_stream(A.hd + ((int64_t)a * n + row));
+        h1 = ld_stream(A.hd + ((int64_t)i1 * n + row));
+        h2 = ld_stream(A.hd + ((int64_t)i2 * n + row));
+        if (A.with_d2) dd = ld_stream(A.d2 + (3 * (int64_t)row + a));
         const double* pr = A.p + PS * (int64_t)(A.lo + row);
         pr0 = pr[0];
         pr1 = pr[1];
@@ -664,7 +687,7 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         }
       }
       // the next tile's column indices (its descriptor has arrived: it was the first load of this iteration)
-      if (tn < xr.end && dn.w <= WG && tid < dn.w) col_n = A.inc_col[dn.z + tid];
+      if (tn < xr.end && dn.w <= WG && tid < dn.w) col_n = ld_stream(A.inc_col + dn.z + tid);
       if (lane_on) {
         if (MODE == 2 || MODE == 3) {
           scr[buf][0][tid] = p0 + 2.0 * p1 + 3.0 * p2;
@@ -682,7 +705,7 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         for (int j = lo; j < hi; ++j) s += scr[buf][a][j];
         const double pa = (a == 0) ? pr0 : (a == 1 ? pr1 : pr2);
         s += h0 * pr0 + h1 * pr1 + h2 * pr2 + dd * pa;
-        A.y[3 * (int64_t)row + a] = s;
+        st_stream(A.y + (3 * (int64_t)row + a), s);
         dot += pa * s;
       }
       for (int idx = tid + WG; idx < nrows * 3; idx += WG) {  // tiles of very low-degree rows (> 85 rows)
@@ -1018,7 +1041,7 @@ __global__ __launch_bounds__(WG) void k_cg_update2(CgVec V, int parity, const do
   double* p = V.p + PS * (int64_t)V.lo;
   for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n3; i += (int64_t)gridDim.x * WG) {
     const int64_t row = i / 3, j = PS * row + (i - 3 * row);
-    p[j] = V.z[i] + beta * p[j];
+    p[j] = ld_stream(V.z + i) + beta * p[j];
   }
 }
 
@@ -1637,7 +1660,7 @@ __device__ __forceinline__ void chain_apply_lean(const double (&W)[CH][9], const
 #pragma unroll
   for (int k = 0; k < CH; ++k)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) S[k][c] = (cs_tile + ((int64_t)c * np + k * 64))[lane];
+    for (int c = 0; c < 6; ++c) S[k][c] = ld_stream(cs_tile + ((int64_t)c * np + k * 64) + lane);
   // ---- forward, chunk map from a zero input: a = t_{CH-1}, F = (-W_{CH-1}) ... (-W_0)
   double a[3] = {ch[0], ch[1], ch[2]}, F[9];
 #pragma unroll
@@ -1761,7 +1784,7 @@ __global__ __launch_bounds__(WG) void k_cg_init_cl(CgVec V, ChainPre C, int n_st
 #pragma unroll
     for (int k = 0; k < CH; ++k)
 #pragma unroll
-      for (int c = 0; c < 9; ++c) W[k][c] = (cw_tile + ((int64_t)c * np + k * 64))[lane];
+      for (int c = 0; c < 9; ++c) W[k][c] = ld_stream(cw_tile + ((int64_t)c * np + k * 64) + lane);
     const double* bt = b + f0;
     double rv[NV];
     if (lim == 3u * TILE) {
@@ -1837,7 +1860,7 @@ __global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n
 #pragma unroll
     for (int k = 0; k < CH; ++k)
 #pragma unroll
-      for (int c = 0; c < 9; ++c) W[k][c] = (cw_tile + ((int64_t)c * np + k * 64))[lane];
+      for (int c = 0; c < 9; ++c) W[k][c] = ld_stream(cw_tile + ((int64_t)c * np + k * 64) + lane);
     double* yt = vy + f0;
     double* rt = vr + f0;
     const double* at = vap + f0;
@@ -1848,9 +1871,9 @@ __global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const unsigned e = lane + 64u * j;
-        rv[j] = rt[e];
-        av[j] = at[e];
-        yv[j] = yt[e];
+        rv[j] = ld_stream(rt + e);
+        av[j] = ld_stream(at + e);
+        yv[j] = ld_stream(yt + e);
         pv[j] = pt[e];
       }
 #pragma unroll
@@ -1861,8 +1884,8 @@ __global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const unsigned e = lane + 64u * j;
-        rt[e] = rv[j];
-        yt[e] = yv[j];
+        st_stream(rt + e, rv[j]);
+        st_stream(yt + e, yv[j]);
       }
     } else {
 #pragma unroll
@@ -1891,7 +1914,7 @@ __global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n
     for (int j = 0; j < NV; ++j) {
       const unsigned e = lane + 64u * j;
       const double z = buf[e + e / (3 * CH)];
-      if (full || e < lim) zt[e] = z;
+      if (full || e < lim) st_stream(zt + e, z);
       rz += rv[j] * z;
     }
     wave_lds_sync();

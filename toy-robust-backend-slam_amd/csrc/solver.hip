@@ -64,6 +64,7 @@ struct pgo_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
+  int64_t device_bytes = 0;
 
   int64_t n_full = 0;  // world * rows_per_rank  (>= N; tail rows are padding)
   // graph
@@ -137,6 +138,7 @@ struct pgo_handle {
   // captured slice of PCG iterations (world == 1)
   hipGraphExec_t cg_graph_exec = nullptr;
   int cg_graph_len = 0;
+  int last_pcg_iters = 0;  // iteration count of the previous PCG solve of this handle (slice scheduling)
   // grids
   int g_edge = 1, g_rows = 1, g_vec = 1, g_flat = 1, g_spmv = 1, g_asm = 1;
 
@@ -173,6 +175,7 @@ struct pgo_handle {
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return fail(PGO_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     allocs.push_back(p);
+    device_bytes += (int64_t)bytes;
     e = hipMemsetAsync(p, 0, bytes, stream);
     if (e != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
     *out = (T*)p;
@@ -503,7 +506,6 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     ia_p.resize(E);
     ib_p.resize(E);
     for (int32_t e = 0; e < E; ++e) {
-      if (ia[e] < 0 || ia[e] >= N || ib[e] < 0 || ib[e] >= N) return fail(PGO_ERR_INVALID_ARG, "edge endpoint out of range");
       ia_p[e] = perm[ia[e]];
       ib_p[e] = perm[ib[e]];
     }
@@ -749,6 +751,7 @@ int pgo_handle::lm_begin() {
   termination = 0;
   radius = opt.radius0;
   decrease_factor = 2.0;
+  last_pcg_iters = 0;
   t_eval = t_asm = t_lin = t_cand = 0;
   recs.clear();
   const double t_begin = wall_s();
@@ -878,19 +881,29 @@ int pgo_handle::pcg(int* iters, double* rel) {
       cg_graph_len = every;
     }
   }
+  // Slices enqueued after convergence are not free: each of their launches early-outs on st->done but still costs
+  // ~4.5 us of device time (13 us per no-op PCG iteration at 1M poses -- with 100-iteration slices that was 5 % of an LM
+  // iteration).  So the slices are short and the FIRST host check comes after as many of them as the previous solve of
+  // this handle makes likely (85 % of its iteration count; consecutive LM iterations need similar counts), the
+  // following checks after every slice.
   int it = 0;
+  int ahead = (last_pcg_iters > 0) ? std::max(1, (int)(0.85 * last_pcg_iters) / every) : 1;
   while (true) {
-    const int chunk = std::min(every, max_it - it);
-    if (use_graph && chunk == every && (it & 1) == 0) {
-      HIPC(hipGraphLaunch(cg_graph_exec, stream));
-    } else {
-      for (int c = 0; c < chunk; ++c) PGOC(enqueue_iteration((it + c) & 1));
+    for (int sl = 0; sl < ahead && it < max_it; ++sl) {
+      const int chunk = std::min(every, max_it - it);
+      if (use_graph && chunk == every && (it & 1) == 0) {
+        HIPC(hipGraphLaunch(cg_graph_exec, stream));
+      } else {
+        for (int c = 0; c < chunk; ++c) PGOC(enqueue_iteration((it + c) & 1));
+      }
+      it += chunk;
     }
-    it += chunk;
+    ahead = 1;
     HIPC(hipMemcpyAsync(h_st, st, sizeof(dev::CgState), hipMemcpyDeviceToHost, stream));
     PGOC(sync());
     if (h_st->done || it >= max_it) break;
   }
+  last_pcg_iters = h_st->iters;
   *iters = h_st->iters;
   *rel = (h_st->bb > 0.0) ? std::sqrt(h_st->rr / h_st->bb) : 0.0;
   return PGO_OK;
@@ -1146,7 +1159,8 @@ void pgo_options_default(pgo_options* o) {
   o->sc_prior_lambda = 1.0;
   o->pose_ordering = -1;
   o->pcg_chain_len = -1;
-  o->halo_overlap = 1;
+  o->halo_exchange = 1;  // point-to-point exchange of the referenced rows; 0 = all-gather
+  o->halo_overlap = 0;   // opt-in: the two-stream schedule has never run against a real peer (no multi-GPU lease yet)
 }
 
 int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
@@ -1165,6 +1179,14 @@ int pgo_create_weighted(pgo_t** h, int32_t n_poses, const double* poses, int32_t
   if (o.method < 0 || o.method > 2)
     return fail(PGO_ERR_UNSUPPORTED, "only METHOD 0 (plain), 1 (DCS) and 2 (switchable constraints) are implemented (reference main.cpp:54-56)");
   if (o.fixed_pose >= n_poses) return fail(PGO_ERR_INVALID_ARG, "fixed_pose out of range");
+  // every endpoint is checked HERE -- before the device is touched and before anything indexes by it
+  // (resolve_chain_len, compute_pose_order and build_shard_structure all do)
+  for (int32_t e = 0; e < n_edges; ++e) {
+    if (ia[e] < 0 || ia[e] >= n_poses || ib[e] < 0 || ib[e] >= n_poses)
+      return fail(PGO_ERR_INVALID_ARG, "edge " + std::to_string(e) + ": endpoint out of range");
+    if (ia[e] == ib[e])
+      return fail(PGO_ERR_INVALID_ARG, "edge " + std::to_string(e) + ": self loop (Ceres rejects duplicate parameter blocks)");
+  }
   PGOC(require_device(device));
   std::unique_ptr<pgo_handle> H(new pgo_handle);
   H->opt = o;
@@ -1392,6 +1414,30 @@ int pgo_solve_batch(pgo_t* const* handles, int32_t n, pgo_summary* summaries, in
   worker();
   for (auto& th : pool) th.join();
   if (first_status != PGO_OK) return fail(first_status, first_msg);
+  return PGO_OK;
+}
+
+int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
+  if (!h || !out) return fail(PGO_ERR_INVALID_ARG, "pgo_get_info: null");
+  memset(out, 0, sizeof *out);
+  out->n_poses = h->S.n_poses;
+  out->n_edges = (int32_t)h->n_edges_total;
+  out->world = h->comm ? h->comm->world : 1;
+  out->rank = h->comm ? h->comm->rank : 0;
+  out->row_lo = h->S.lo;
+  out->row_hi = h->S.hi;
+  out->n_edges_local = h->S.n_edges_local;
+  out->n_tiles = h->S.n_tiles();
+  out->n_incidences = h->S.n_inc;
+  out->pcg_block_poses = h->grp_B;
+  out->pcg_chain_len = h->chain_len;
+  out->chain_kernel = h->chain_chunk;
+  out->pose_ordering = h->perm.empty() ? 0 : 1;
+  out->halo_exchange = h->use_halo ? 1 : 0;
+  out->halo_overlap = h->overlap ? 1 : 0;
+  out->halo_send_rows = (int64_t)h->S.halo_send_row.size();
+  out->halo_recv_rows = (int64_t)h->S.halo_recv_row.size();
+  out->device_bytes = h->device_bytes;
   return PGO_OK;
 }
 
