@@ -2,7 +2,7 @@
 # bench (20 steps after 5) + in-loop kernel times of the current build
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 200 python bench.py --steps 20 --warmup 5 --cpu-iters 0 "$@" > gpurun_out/exp_bench.json 2> gpurun_out/exp_bench.err || { tail -5 gpurun_out/exp_bench.err; exit 1; }
+timeout -k 10 200 python bench.py --steps 20 --warmup 5 --cpu-iters 0 --workloads 0 "$@" > gpurun_out/exp_bench.json 2> gpurun_out/exp_bench.err || { tail -5 gpurun_out/exp_bench.err; exit 1; }
 python - <<PY
 import json
 d = json.load(open("gpurun_out/exp_bench.json"))

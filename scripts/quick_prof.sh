@@ -4,7 +4,7 @@ set -o pipefail
 OUT=gpurun_out/quick_prof
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 --kernel-reps 3 "$@" > $OUT/log.txt 2>&1 || { tail -5 $OUT/log.txt; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 --workloads 0 --passes 1 --kernel-reps 3 "$@" > $OUT/log.txt 2>&1 || { tail -5 $OUT/log.txt; exit 1; }
 python3 - <<PY
 import csv, glob
 from collections import defaultdict

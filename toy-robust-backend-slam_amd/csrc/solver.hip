@@ -681,9 +681,10 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     HIPC(hipMemsetAsync(chain_w, 0, (size_t)9 * chain_pad * sizeof(double), stream));
     HIPC(hipMemsetAsync(chain_s, 0, (size_t)6 * chain_pad * sizeof(double), stream));
     g_chain = (int)std::min<int64_t>((NL + 4 * dev::CHAIN_TILE - 1) / (4 * dev::CHAIN_TILE), 2048);
-    // apply kernel: the lean form (one DPP-shift recurrence step per lane of a segment) for segments of <= 64 poses, the
-    // log-depth scan form for longer ones; PGO_CHAIN_KERNEL = scan | lean2 | lean4 overrides (experiments)
-    chain_chunk = chain_len <= 64 ? 2 : 0;
+    // apply kernel: the lean form (one DPP-shift recurrence step per lane of a segment), 2 poses per lane for segments of
+    // <= 64 poses, 4 for longer ones (INTEL, chain-256: 20 us per apply in the scan form -- five 256-row tiles, latency-
+    // bound -- of a 30 us PCG iteration); PGO_CHAIN_KERNEL = scan | lean2 | lean4 overrides (experiments)
+    chain_chunk = chain_len <= 64 ? 2 : 4;   // 4: segments of up to 256 poses (the small chain-like graphs)
     if (const char* ck = getenv("PGO_CHAIN_KERNEL")) {
       if (!strcmp(ck, "scan")) chain_chunk = 0;
       else if (!strcmp(ck, "lean2") && (128 % chain_len) == 0) chain_chunk = 2;
