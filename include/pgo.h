@@ -277,6 +277,28 @@ int pgo_solve(pgo_t* h, pgo_summary* s);                                        
  * overlap on the device; each handle's result is bitwise what pgo_solve alone gives.  summaries: n entries or NULL.
  * Handles with a communicator are refused (PGO_ERR_UNSUPPORTED).  Returns the first failing status.                */
 int pgo_solve_batch(pgo_t* const* handles, int32_t n, pgo_summary* summaries, int32_t max_concurrency);   /* [gpu] */
+/* The batch as ONE handle (what the layer managers' evaluate_layer_cost / optimize_layer / optimize_local_window loops
+ * want, src/simple_layer_manager.cpp:457-622): the block-diagonal union of n independent problems.  One launch of the
+ * fused edge kernel, of the assembly kernel and of the preconditioner set-up covers every problem; each problem's linear
+ * system is solved by its own workgroup in a single launch (the whole PCG solve, device-resident scalars); radius, cost,
+ * accept / reject and termination are kept per problem and every problem stops by its own tests.  About ten launches per
+ * LM iteration for the whole batch.  Every problem's result equals what pgo_solve gives for it alone up to the
+ * association of floating-point sums.  One set of options for all problems: METHOD 0 or 1, opt->fixed_pose = the
+ * constant pose of EVERY problem (its own numbering), preconditioner = chain segments (what the library would choose for
+ * the largest problem alone; 64-pose segments where that would be dense pose blocks) or pcg_block_poses = 1.
+ * Not supported (PGO_ERR_UNSUPPORTED): METHOD 2, info_weighting, a row with more than 256 incident edges, a communicator. */
+typedef struct pgo_batch pgo_batch_t;
+int pgo_batch_create(pgo_batch_t** b, int32_t n_problems, const pgo_graph* const* graphs,
+                     const pgo_options* opt, int device);                          /* [gpu] */
+void pgo_batch_destroy(pgo_batch_t* b);
+int32_t pgo_batch_size(const pgo_batch_t* b);
+/* ceres::Solve on every problem; summaries: n entries or NULL */
+int pgo_batch_solve(pgo_batch_t* b, pgo_summary* summaries);                      /* [gpu] */
+int pgo_batch_get_poses(pgo_batch_t* b, int32_t problem, double* out_xyt);        /* [gpu] */
+int pgo_batch_set_poses(pgo_batch_t* b, int32_t problem, const double* poses_xyt); /* [gpu] */
+int32_t pgo_batch_num_iter_records(const pgo_batch_t* b, int32_t problem);
+int pgo_batch_get_iter_records(const pgo_batch_t* b, int32_t problem, pgo_iter_record* out, int32_t cap);
+
 /* the same minimiser, resumable: (re)start with pgo_lm_begin, then run LM
  * iterations in slices (bench.py times slices); returns *done != 0 once a
  * termination test fired.                                                        */

@@ -799,6 +799,81 @@ def test_solve_batch_equals_individual_solves(pgo):
         s.close()
 
 
+def test_batch_handle_equals_individual_solves(pgo):
+    """pgo_batch_*: 64 layer problems (32 full INTEL copies with different loop-edge subsets, 32 windows; plain functor +
+    Huber, anchored first pose, 2 LM iterations -- the reference's evaluate_layer_cost / optimize_layer pattern,
+    src/simple_layer_manager.cpp:457-622) in ONE handle: every problem equals its own pgo_solve (poses 1e-9, cost 1e-10
+    relative, same accept/reject history), and the batch is at least 5x the throughput of the thread-pool pgo_solve_batch."""
+    import time
+    graphs = _layer_problems(pgo, 64)
+    opt = dict(method=0, max_iters=2, fixed_pose=0)
+    single = [pgo.Solver(g, pgo.Options(**opt)) for g in graphs]
+    pgo.solve_batch(single[:2], 2)                                    # warm-up of the code path
+    for s, g in zip(single[:2], graphs[:2]):
+        s.set_poses(np.array(g.poses))
+    t = time.perf_counter()
+    s_pool = pgo.solve_batch(single, 8)
+    t_pool = time.perf_counter() - t
+    b = pgo.Batch(graphs, pgo.Options(**opt))
+    b.solve()                                                         # warm-up
+    for k, g in enumerate(graphs):
+        b.set_poses(k, np.array(g.poses))
+    t = time.perf_counter()
+    s_b = b.solve()
+    t_b = time.perf_counter() - t
+    print(f"64 layer problems, 2 LM iterations each: thread pool (8 threads, one handle per problem) {t_pool*1e3:.1f} ms, "
+          f"one batched handle {t_b*1e3:.1f} ms  ({t_pool/t_b:.1f}x)")
+    worst = 0.0
+    for k, (s, sa, sb) in enumerate(zip(single, s_pool, s_b)):
+        assert sa.iterations == sb.iterations and sa.termination == sb.termination, k
+        assert sb.initial_cost == pytest.approx(sa.initial_cost, rel=1e-12)
+        assert sb.final_cost == pytest.approx(sa.final_cost, rel=1e-10)
+        ra, rb = s.iter_records(), b.iter_records(k)
+        assert [r["step_ok"] for r in ra] == [r["step_ok"] for r in rb]
+        d = np.abs(s.poses() - b.poses(k)).max()
+        worst = max(worst, d)
+        assert d < 1e-9, (k, d)
+    print(f"max |d pose| batch vs individual solves: {worst:.2e}")
+    assert t_pool / t_b >= 5.0
+    for s in single:
+        s.close()
+    b.close()
+
+
+def test_batch_handle_runs_to_convergence_and_other_modes(pgo):
+    """problems of one batch stop by their own tests: full 50-iteration DCS solves of three datasets in one handle against
+    the golden direct-solve fixtures; plus the 3x3 block-Jacobi form and the unsupported modes"""
+    names = [("INTEL", 50), ("MIT", 0), ("CSAIL", 0), ("INTEL", 0)]
+    graphs = [load(pgo, nm, k) for nm, k in names]
+    b = pgo.Batch(graphs, pgo.Options(method=1, pcg_max_iters=400000))
+    summ = b.solve()
+    for k, (nm, n_out) in enumerate(names):
+        tag = "%s_out%d_m1" % (nm, n_out)
+        fx = json.load(open(os.path.join(GOLDEN, "lm_%s.json" % tag)))
+        ref = np.load(os.path.join(GOLDEN, "lm_%s_poses.npy" % tag))
+        assert summ[k].termination == fx["termination"] and summ[k].iterations == fx["iterations"]
+        assert summ[k].final_cost == pytest.approx(fx["final_cost"], rel=1e-7)
+        d = np.abs(b.poses(k)[:, :2] - ref[:, :2]).max()
+        print(f"batch problem {tag}: max |d translation| vs golden {d:.2e}, PCG iterations {summ[k].total_pcg_iters}")
+        assert d < 5e-6
+        assert [r["step_ok"] for r in b.iter_records(k)] == [r["step_ok"] for r in fx["records"]]
+    b.close()
+    # 3x3 block-Jacobi inside the one-workgroup solve
+    g2 = _layer_problems(pgo, 4)
+    b1 = pgo.Batch(g2, pgo.Options(method=0, max_iters=2, pcg_block_poses=1, pcg_chain_len=0))
+    s1 = b1.solve()
+    for k, g in enumerate(g2):
+        s = pgo.Solver(g, pgo.Options(method=0, max_iters=2, pcg_block_poses=1, pcg_chain_len=0))
+        ss = s.solve()
+        assert ss.final_cost == pytest.approx(s1[k].final_cost, rel=1e-10) and np.abs(s.poses() - b1.poses(k)).max() < 1e-9
+        s.close()
+    b1.close()
+    for kw in (dict(method=2), dict(info_weighting=1), dict(pcg_block_poses=4)):
+        with pytest.raises(pgo.PgoError) as e:
+            pgo.Batch(g2, pgo.Options(**kw))
+        assert e.value.status == -8
+
+
 def test_solve_batch_errors_and_empty(pgo):
     import ctypes as C
     assert pgo.solve_batch([]) == []

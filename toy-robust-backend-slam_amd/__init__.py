@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _build
 
-__all__ = ["PgoError", "Options", "Summary", "IterRecord", "ReadG2O", "Graph", "Solver", "Comm", "lib", "build",
+__all__ = ["PgoError", "Options", "Summary", "IterRecord", "ReadG2O", "Graph", "Solver", "Batch", "Comm", "lib", "build",
            "HandleInfo", "synth_manhattan", "solve_batch", "shard_plan", "shard_halo", "pose_order", "KernelStats", "EXPORTS", "TERMINATION"]
 
 EDGE_ODOMETRY, EDGE_CLOSURE, EDGE_BOGUS = 0, 1, 2
@@ -36,7 +36,9 @@ EXPORTS = [
     "pgo_graph_edge_kind", "pgo_inject_outliers", "pgo_write_nodes", "pgo_write_edges", "pgo_write_g2o",
     "pgo_synth_manhattan", "pgo_options_default",
     "pgo_comm_unique_id", "pgo_comm_create_rccl", "pgo_comm_create_shm", "pgo_comm_destroy",
-    "pgo_create", "pgo_create_weighted", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_edge_chi2", "pgo_solve", "pgo_solve_batch", "pgo_lm_begin", "pgo_lm_step",
+    "pgo_create", "pgo_create_weighted", "pgo_create_from_graph", "pgo_destroy", "pgo_eval", "pgo_edge_chi2", "pgo_solve", "pgo_solve_batch",
+    "pgo_batch_create", "pgo_batch_destroy", "pgo_batch_size", "pgo_batch_solve", "pgo_batch_get_poses", "pgo_batch_set_poses",
+    "pgo_batch_num_iter_records", "pgo_batch_get_iter_records", "pgo_lm_begin", "pgo_lm_step",
     "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_info", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
     "pgo_write_switches",
     "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_bench_precond", "pgo_debug_precond", "pgo_debug_spmv", "pgo_debug_normal_eq",
@@ -173,6 +175,17 @@ def lib():
     L.pgo_solve_batch.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(Summary), C.c_int32]
     L.pgo_destroy.argtypes = [vp]
     L.pgo_destroy.restype = None
+    L.pgo_batch_create.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(vp), C.POINTER(Options), C.c_int]
+    L.pgo_batch_destroy.argtypes = [vp]
+    L.pgo_batch_destroy.restype = None
+    L.pgo_batch_size.argtypes = [vp]
+    L.pgo_batch_size.restype = C.c_int32
+    L.pgo_batch_solve.argtypes = [vp, C.POINTER(Summary)]
+    L.pgo_batch_get_poses.argtypes = [vp, C.c_int32, dp]
+    L.pgo_batch_set_poses.argtypes = [vp, C.c_int32, dp]
+    L.pgo_batch_num_iter_records.argtypes = [vp, C.c_int32]
+    L.pgo_batch_num_iter_records.restype = C.c_int32
+    L.pgo_batch_get_iter_records.argtypes = [vp, C.c_int32, C.POINTER(IterRecord), C.c_int32]
     L.pgo_eval.argtypes = [vp, dp, C.c_int, dp, dp, dp]
     L.pgo_solve.argtypes = [vp, C.POINTER(Summary)]
     L.pgo_lm_begin.argtypes = [vp]
@@ -411,6 +424,52 @@ def solve_batch(solvers, max_concurrency: int = 8):
     out = (Summary * max(n, 1))()
     _check(lib().pgo_solve_batch(hs, n, out, max_concurrency))
     return [out[i] for i in range(n)]
+
+
+class Batch:
+    """pgo_batch_*: ONE handle over the block-diagonal union of independent problems (the layer managers' many small
+    ceres::Solve calls, reference src/simple_layer_manager.cpp:457-622); per-problem LM state, one workgroup per problem
+    for the linear solves."""
+
+    def __init__(self, graphs, options: "Options | None" = None, device: int = 0):
+        self.graphs = list(graphs)
+        self.options = options if options is not None else Options()
+        n = len(self.graphs)
+        hs = (C.c_void_p * max(n, 1))(*[g._h for g in self.graphs])
+        self._h = C.c_void_p()
+        _check(lib().pgo_batch_create(C.byref(self._h), n, hs, C.byref(self.options), device))
+        self.n = n
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pgo_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self):
+        out = (Summary * max(self.n, 1))()
+        _check(lib().pgo_batch_solve(self._h, out))
+        return [out[i] for i in range(self.n)]
+
+    def poses(self, k: int):
+        out = np.zeros((self.graphs[k].n_poses, 3))
+        _check(lib().pgo_batch_get_poses(self._h, k, _dp(out)))
+        return out
+
+    def set_poses(self, k: int, poses):
+        p = np.ascontiguousarray(poses, np.float64)
+        _check(lib().pgo_batch_set_poses(self._h, k, _dp(p)))
+
+    def iter_records(self, k: int):
+        n = lib().pgo_batch_num_iter_records(self._h, k)
+        arr = (IterRecord * max(n, 1))()
+        _check(lib().pgo_batch_get_iter_records(self._h, k, arr, n))
+        return [arr[i].as_dict() for i in range(n)]
 
 
 class Solver:

@@ -61,6 +61,19 @@ __device__ __forceinline__ void st_stream(T* p, T v) {
 #endif
 }
 
+// the same under a template switch: kernels whose phases hand data to each other through global memory INSIDE one
+// workgroup (solo.hip.h) must use plain accesses (an nt load bypasses the CU's L1, a plain one may not)
+template <bool NT, class T>
+__device__ __forceinline__ T ld_sel(const T* p) {
+  if constexpr (NT) return ld_stream(p);
+  else return *p;
+}
+template <bool NT, class T>
+__device__ __forceinline__ void st_sel(T* p, T v) {
+  if constexpr (NT) st_stream(p, v);
+  else *p = v;
+}
+
 // ------------------------------------------------- layout of the off-diagonal blocks
 // AoSoA: incidences in groups of 64 (one wave), 9 values x 64 lanes contiguous (4608 B per group), so
 // that a wave's 9 coalesced 512-byte accesses fall into ONE contiguous 4.5 KiB region instead of nine
@@ -199,6 +212,9 @@ struct EdgeArgs {
   // information matrices, 6 planes [6][n_edges]: I11 I12 I13 I22 I23 I33 (include/graph.h:41-47); nullptr when the handle
   // was created without them.  Read by k_edge_eval<*, true> and k_edge_chi2 only.
   const double* info;
+  // batched handles: cost of every edge (NaN where the residual or Jacobian is not finite), summed per problem by
+  // k_prob_reduce; nullptr otherwise
+  double* cost_out;
 };
 
 // Cholesky factor of a 3x3 information matrix, Omega = L L' (positive definiteness is checked on the host at create)
@@ -376,6 +392,7 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
       }
     }
     if (!finite) atomicOr(bad, 1);
+    if (A.cost_out) A.cost_out[e] = finite ? ((fl & 2u) ? ecost : 0.0) : __builtin_nan("");
   }
   if (WITH_JAC) {
     // transpose through LDS so that the 112-byte records leave as 16-byte-per-lane
@@ -822,10 +839,12 @@ __global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
 
 // Jacobi column scaling 1/(1 + ||J col||) from the unscaled diagonal (Ceres
 // TrustRegionMinimizer, iteration 0); 0 on the constant pose.
+// fixed_mask (batched handles: one anchored pose per problem + the padding rows): nullptr = only pose `fixed` is constant
 __global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo, int fixed, int enabled,
-                               double* __restrict__ scale) {
+                               double* __restrict__ scale, const uint8_t* __restrict__ fixed_mask) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_loc) return;
+  if (fixed_mask && fixed_mask[row]) fixed = lo + row;
   const int64_t n = n_loc;
   double s0 = 1.0, s1 = 1.0, s2 = 1.0;
   if (enabled) {
@@ -843,10 +862,16 @@ __global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo,
 // LM diagonal D'D = clamp(diag(H), min, max) / radius and the block-Jacobi
 // preconditioner M^-1 = (H_ii + D'D)^-1  (symmetric 3x3, 6 planes).
 // diag_full (METHOD 2): the UNREDUCED squared column norms the LM diagonal is defined on; nullptr = hd's diagonal
+// Batched handles: the trust-region radius is per problem -- prob_radius[prob_of_256[row >> 8]] (problems start at
+// multiples of 256 rows) -- and fixed_mask marks each problem's anchored pose and the padding rows.
 __global__ void k_prepare(const double* __restrict__ hd, const double* __restrict__ diag_full, int n_loc, int lo, int fixed,
-                          double radius, double dmin, double dmax, double* __restrict__ d2, double* __restrict__ minv) {
+                          double radius, double dmin, double dmax, double* __restrict__ d2, double* __restrict__ minv,
+                          const uint8_t* __restrict__ fixed_mask, const int32_t* __restrict__ prob_of_256,
+                          const double* __restrict__ prob_radius) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_loc) return;
+  if (fixed_mask && fixed_mask[row]) fixed = lo + row;
+  if (prob_radius) radius = prob_radius[prob_of_256[row >> 8]];
   const int64_t n = n_loc;
   double a00 = hd[row], a01 = hd[n + row], a02 = hd[2 * n + row], a11 = hd[3 * n + row], a12 = hd[4 * n + row],
          a22 = hd[5 * n + row];
@@ -1675,15 +1700,18 @@ __device__ __forceinline__ double wave_next(double v) {
 // In place on the lane's chunk `ch` of the wave-private LDS tile (pose k, component c at 3 k + c): r on entry, z = M^-1 r
 // on exit.  W: this lane's W_k (registers, loaded by the caller).  csl: S^-1 planes at this lane (+ c * np + k * 64).
 // n_steps = lanes per segment - 1.
-template <int CH>
+// scan_levels > 0: the recurrence over the lanes runs as that many Hillis-Steele levels of (vector, matrix) pairs instead of
+// n_steps serial shifts -- for few, long segments (256 poses = 64 lanes: 6 levels against 63 dependent steps), where
+// nothing else is in flight to hide the serial chain (solo.hip.h).
+template <int CH, bool NT = true>
 __device__ __forceinline__ void chain_apply_lean(const double (&W)[CH][9], const double* __restrict__ cs_tile, int64_t np,
-                                                 unsigned lane, double* __restrict__ ch, int n_steps) {
+                                                 unsigned lane, double* __restrict__ ch, int n_steps, int scan_levels = 0) {
   // S^-1 (uniform plane base + lane): issued now, consumed after the forward recurrence
   double S[CH][6];
 #pragma unroll
   for (int k = 0; k < CH; ++k)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) S[k][c] = ld_stream(cs_tile + ((int64_t)c * np + k * 64) + lane);
+    for (int c = 0; c < 6; ++c) S[k][c] = ld_sel<NT>(cs_tile + ((int64_t)c * np + k * 64) + lane);
   // ---- forward, chunk map from a zero input: a = t_{CH-1}, F = (-W_{CH-1}) ... (-W_0)
   double a[3] = {ch[0], ch[1], ch[2]}, F[9];
 #pragma unroll
@@ -1705,11 +1733,24 @@ __device__ __forceinline__ void chain_apply_lean(const double (&W)[CH][9], const
   }
   // ---- recurrence over the lanes: x_l = a_l + F_l x_{l-1}
   double x0 = a[0], x1 = a[1], x2 = a[2];
-  for (int s = 0; s < n_steps; ++s) {
-    const double p0 = wave_prev(x0), p1 = wave_prev(x1), p2 = wave_prev(x2);
-    x0 = a[0] + (F[0] * p0 + F[1] * p1 + F[2] * p2);
-    x1 = a[1] + (F[3] * p0 + F[4] * p1 + F[5] * p2);
-    x2 = a[2] + (F[6] * p0 + F[7] * p1 + F[8] * p2);
+  if (scan_levels > 0) {
+    double t[3] = {x0, x1, x2};
+    for (int lv = 0, off = 1; lv < scan_levels; ++lv, off <<= 1) {
+      double bb[3], N[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bb[k] = __shfl_up(t[k], off, 64);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) N[c] = __shfl_up(F[c], off, 64);
+      if ((int)lane >= off) affine_compose(t, F, bb, N, true);
+    }
+    x0 = t[0]; x1 = t[1]; x2 = t[2];
+  } else {
+    for (int s = 0; s < n_steps; ++s) {
+      const double p0 = wave_prev(x0), p1 = wave_prev(x1), p2 = wave_prev(x2);
+      x0 = a[0] + (F[0] * p0 + F[1] * p1 + F[2] * p2);
+      x1 = a[1] + (F[3] * p0 + F[4] * p1 + F[5] * p2);
+      x2 = a[2] + (F[6] * p0 + F[7] * p1 + F[8] * p2);
+    }
   }
   // ---- forward, true sweep from the end of the previous chunk; u = S^-1 t kept in registers
   double U[CH][3];
@@ -1753,11 +1794,24 @@ __device__ __forceinline__ void chain_apply_lean(const double (&W)[CH][9], const
     for (int c = 0; c < 9; ++c) G[c] = R[c];
   }
   double y0 = b[0], y1 = b[1], y2 = b[2];
-  for (int s = 0; s < n_steps; ++s) {
-    const double p0 = wave_next(y0), p1 = wave_next(y1), p2 = wave_next(y2);
-    y0 = b[0] + (G[0] * p0 + G[1] * p1 + G[2] * p2);
-    y1 = b[1] + (G[3] * p0 + G[4] * p1 + G[5] * p2);
-    y2 = b[2] + (G[6] * p0 + G[7] * p1 + G[8] * p2);
+  if (scan_levels > 0) {
+    double t[3] = {y0, y1, y2};
+    for (int lv = 0, off = 1; lv < scan_levels; ++lv, off <<= 1) {
+      double bb[3], N[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bb[k] = __shfl_down(t[k], off, 64);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) N[c] = __shfl_down(G[c], off, 64);
+      if ((int)lane + off < 64) affine_compose(t, G, bb, N, true);
+    }
+    y0 = t[0]; y1 = t[1]; y2 = t[2];
+  } else {
+    for (int s = 0; s < n_steps; ++s) {
+      const double p0 = wave_next(y0), p1 = wave_next(y1), p2 = wave_next(y2);
+      y0 = b[0] + (G[0] * p0 + G[1] * p1 + G[2] * p2);
+      y1 = b[1] + (G[3] * p0 + G[4] * p1 + G[5] * p2);
+      y2 = b[2] + (G[6] * p0 + G[7] * p1 + G[8] * p2);
+    }
   }
   {
     double z0 = wave_next(y0), z1 = wave_next(y1), z2 = wave_next(y2);
@@ -2061,6 +2115,51 @@ __global__ __launch_bounds__(WG) void k_switch_backsub(SwitchArrays W, const int
   if (threadIdx.x == 0) {
     part_model[blockIdx.x] = pm;
     part_step2[blockIdx.x] = ps;
+  }
+}
+
+// ------------------------------------------------- batched handles: per-problem reductions and acceptance
+struct ProbRange {
+  int32_t row0, nrows;   // rows [row0, row0 + nrows)
+  int32_t e0, e1;        // local edges [e0, e1)
+};
+struct ProbSums {
+  double cost, gmax, xnorm2;
+};
+// one workgroup per problem, fixed summation order (thread-strided partials, then the workgroup tree)
+__global__ __launch_bounds__(WG) void k_prob_reduce(const ProbRange* __restrict__ pr, const double* __restrict__ edge_cost,
+                                                    const double* __restrict__ gs, const double* __restrict__ scale,
+                                                    const double* __restrict__ x, int lo, ProbSums* __restrict__ out) {
+  __shared__ double red[8];
+  const ProbRange P = pr[blockIdx.x];
+  double c = 0.0, gm = 0.0, xn = 0.0;
+  if (edge_cost)
+    for (int e = P.e0 + threadIdx.x; e < P.e1; e += WG) c += edge_cost[e];
+  const int64_t f0 = 3 * (int64_t)P.row0, fn = 3 * (int64_t)P.nrows;
+  for (int64_t i = threadIdx.x; i < fn; i += WG) {
+    const double sc = scale[3 * (int64_t)lo + f0 + i];
+    if (sc > 0.0) {
+      if (gs) gm = fmax(gm, fabs(gs[f0 + i] / sc));
+      const double xv = x[3 * (int64_t)lo + f0 + i];
+      xn += xv * xv;
+    }
+  }
+  c = block_sum_bcast(c, red);
+  gm = block_max_bcast(gm, red);
+  xn = block_sum_bcast(xn, red);
+  if (threadIdx.x == 0) {
+    out[blockIdx.x].cost = c;
+    out[blockIdx.x].gmax = gm;
+    out[blockIdx.x].xnorm2 = xn;
+  }
+}
+// x <- cand on the rows of the accepted problems
+__global__ void k_accept_rows(int n_loc, int lo, const int32_t* __restrict__ prob_of_256, const int32_t* __restrict__ accept,
+                              const double* __restrict__ cand, double* __restrict__ x) {
+  const int64_t n3 = 3 * (int64_t)n_loc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / 3);
+    if (accept[prob_of_256[row >> 8]]) x[3 * (int64_t)lo + i] = cand[3 * (int64_t)lo + i];
   }
 }
 

@@ -78,7 +78,7 @@ inline int32_t rows_per_rank(int32_t n_poses, int world, int row_align) {
 
 int build_shard_structure(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
                           const double* meas, const uint8_t* kind, int method, int world, int rank, int row_align,
-                          ShardStructure* out);
+                          ShardStructure* out, const std::vector<int32_t>* tile_breaks = nullptr);
 
 // processing order of the row tiles for K3 (structure.cpp): order[k] = tile that takes the k-th turn
 void compute_tile_order(const ShardStructure& S, std::vector<int32_t>* order);

@@ -27,6 +27,7 @@
 
 #include "comm.h"
 #include "kernels.hip.h"
+#include "solo.hip.h"
 #include "pgo_internal.h"
 
 using pgo::fail;
@@ -139,6 +140,20 @@ struct pgo_handle {
   hipGraphExec_t cg_graph_exec = nullptr;
   int cg_graph_len = 0;
   int last_pcg_iters = 0;  // iteration count of the previous PCG solve of this handle (slice scheduling)
+  // batched handle (pgo_batch_*): the block-diagonal union of independent problems, each starting at a multiple of 256 rows
+  bool batch_mode = false;
+  std::vector<uint8_t> fixed_mask_h;    // set before create(): constant rows (one anchor per problem + the padding rows)
+  std::vector<int32_t> tile_breaks_h;   // set before create(): rows at which a row tile must start (problem starts)
+  uint8_t* fixed_mask = nullptr;
+  int32_t* prob_of_256 = nullptr;       // problem of each 256-row block
+  double* prob_radius = nullptr;        // trust-region radius per problem
+  double* edge_cost = nullptr;          // cost per local edge (k_edge_eval -> k_prob_reduce)
+  // small graphs: the whole PCG solve of an LM iteration as ONE launch, one workgroup (solo.hip.h)
+  bool solo = false;
+  dev::SoloProb* solo_prob = nullptr;
+  dev::SoloOut* solo_out = nullptr;
+  dev::SoloOut* h_solo = nullptr;  // pinned
+  int solo_steps = 0, solo_scan = 0;
   // grids
   int g_edge = 1, g_rows = 1, g_vec = 1, g_flat = 1, g_spmv = 1, g_asm = 1;
 
@@ -158,6 +173,7 @@ struct pgo_handle {
     if (cg_graph_exec) (void)hipGraphExecDestroy(cg_graph_exec);
     if (h_st) (void)hipHostFree(h_st);
     if (h_scal) (void)hipHostFree(h_scal);
+    if (h_solo) (void)hipHostFree(h_solo);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -261,6 +277,7 @@ struct pgo_handle {
     A.sw_js = sw_js;
     A.sc_lambda = opt.sc_prior_lambda;
     A.info = e_info;
+    A.cost_out = edge_cost;
     return A;
   }
   dev::SwitchArrays switch_arrays() const {
@@ -459,6 +476,8 @@ struct pgo_handle {
   int refresh_switch_system();
   int lm_begin();
   int lm_iteration(bool* stop);
+  int lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, double t0, int k_it, double rel);
+  int prepare_system();
   int pcg(int* iters, double* rel);
   void fill_summary(pgo_summary* s) const;
 };
@@ -516,7 +535,8 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     poses_h = poses_p.data();
     if (fixed_internal >= 0) fixed_internal = perm[fixed_internal];
   }
-  PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, chain_len ? chain_len : grp_B, &S));
+  PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, chain_len ? chain_len : grp_B, &S,
+                                  tile_breaks_h.empty() ? nullptr : &tile_breaks_h));
   HIPC(hipSetDevice(device));
   HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   n_full = (int64_t)world * S.rows_per_rank;
@@ -597,7 +617,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     std::vector<int4> desc((size_t)std::max(1, S.n_tiles()));
     std::vector<int32_t> order;
     const char* to = getenv("PGO_TILE_ORDER");
-    if (!(to && to[0] == '0') && S.n_tiles() >= 4096) pgo::compute_tile_order(S, &order);
+    if (!(to && to[0] == '0') && S.n_tiles() >= 4096 && !batch_mode) pgo::compute_tile_order(S, &order);  // (a batch keeps each problem's tiles together)
     for (int k = 0; k < S.n_tiles(); ++k) {
       const int t = order.empty() ? k : order[k];
       const int32_t r0 = S.tile_row[t], r1 = S.tile_row[t + 1];
@@ -698,6 +718,40 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   } else {
     chain_len = 0;
   }
+  // One-workgroup PCG (solo.hip.h): a single rank, a chain or 3x3 block-Jacobi preconditioner, no chunked heavy row.
+  {
+    const char* se = getenv("PGO_SOLO");
+    // a single graph takes this path only on request (PGO_SOLO=1): one CU's L1 paces the solve -- INTEL 36 us per PCG
+    // iteration against 27 us for the three-kernel loop on 256 CUs, MIT / FR079 8 % faster -- the win is the BATCH, where
+    // every problem has a CU of its own
+    bool ok = world == 1 && !force_collectives && grp_B == 1 && NL > 0 &&
+              (batch_mode || ((se && se[0] == '1') && S.n_tiles() <= 64));
+    for (int t = 0; ok && t < S.n_tiles(); ++t)
+      ok = S.inc_ptr[S.tile_row[t + 1]] - S.inc_ptr[S.tile_row[t]] <= dev::WG;
+    if (ok && chain_len) {
+      chain_chunk = dev::SOLO_CH;  // the 256-row tile layout of the factor planes
+      chain_steps = chain_len / chain_chunk - 1;
+      const int64_t n_wt = (NL + 64 * chain_chunk - 1) / (64 * chain_chunk);
+      g_chain = (int)std::min<int64_t>((n_wt + 3) / 4, 2048);
+      const int lanes = chain_len / dev::SOLO_CH;  // lanes per segment: serial recurrence up to 16, else log-depth scan
+      solo_steps = lanes - 1;
+      solo_scan = 0;
+      if (lanes > 16)
+        for (int l = 1; l < lanes; l <<= 1) ++solo_scan;
+    }
+    if (batch_mode && !ok) return fail(PGO_ERR_UNSUPPORTED, "pgo_batch: a problem has a row with more than 256 incidences");
+    if (ok && !batch_mode) {
+      PGOC(dalloc(&solo_prob, 1));
+      PGOC(dalloc(&solo_out, 1));
+      HIPC(hipHostMalloc((void**)&h_solo, sizeof(dev::SoloOut)));
+    }
+    solo = ok;
+  }
+  if (!fixed_mask_h.empty()) {
+    PGOC(dalloc(&fixed_mask, (int64_t)fixed_mask_h.size()));
+    PGOC(upload(fixed_mask, fixed_mask_h));
+  }
+  if (batch_mode) PGOC(dalloc(&edge_cost, std::max<int64_t>(EL, 1)));
   return sync();
 }
 
@@ -767,7 +821,7 @@ int pgo_handle::lm_begin() {
     PGOC(sync());  // `ones` dies with this scope
   }
   // pass 1: unit scales (0 on the constant pose) -> column norms for Jacobi scaling
-  hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 0, scale);
+  hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 0, scale, (const uint8_t*)fixed_mask);
   PGOC(check_launch("k_jacobi_scale"));
   PGOC(allgather(scale));
   PGOC(linearize(false));
@@ -778,7 +832,7 @@ int pgo_handle::lm_begin() {
     PGOC(check_launch("k_switch_scale"));
   }
   if (opt.jacobi_scaling) {
-    hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 1, scale);
+    hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 1, scale, (const uint8_t*)fixed_mask);
     PGOC(check_launch("k_jacobi_scale"));
     PGOC(allgather(scale));
     PGOC(linearize(true));  // the records do not depend on the scales: re-assemble only
@@ -817,6 +871,38 @@ int pgo_handle::lm_begin() {
 // block-Jacobi PCG on (H + D2) y = gs, y0 = 0.  Host checks the residual every
 // pcg_check_every iterations; in between the kernels early-out on st->done.
 int pgo_handle::pcg(int* iters, double* rel) {
+  if (solo) {
+    dev::SoloProb P;
+    P.row0 = 0;
+    P.nrows = S.n_loc;
+    P.tile0 = 0;
+    P.ntiles = S.n_tiles();
+    P.active = 1;
+    P.max_it = std::max(0, opt.pcg_max_iters);
+    P.rtol = opt.pcg_rtol;
+    HIPC(hipMemcpyAsync(solo_prob, &P, sizeof P, hipMemcpyHostToDevice, stream));
+    dev::SoloArgs A;
+    A.A = spmv_args(p_full, ap, part[0], 1, nullptr);
+    A.V = cg_vec();
+    A.C = chain_pre();
+    if (!chain_len) A.C.cw = nullptr;
+    A.chain_steps = solo_steps;
+    A.scan_levels = solo_scan;
+    A.b = gs;
+    A.prob = solo_prob;
+    A.out = solo_out;
+    A.x = poses;
+    A.scale = scale;
+    A.cand = cand;
+    hipLaunchKernelGGL(dev::k_pcg_solo, dim3(1), dim3(dev::SOLO_WG), 0, stream, A);
+    PGOC(check_launch("k_pcg_solo"));
+    HIPC(hipMemcpyAsync(h_solo, solo_out, sizeof(dev::SoloOut), hipMemcpyDeviceToHost, stream));
+    PGOC(sync());  // P (stack) was consumed by the copy above
+    *iters = h_solo->iters;
+    *rel = (h_solo->bb > 0.0) ? std::sqrt(h_solo->rr / h_solo->bb) : 0.0;
+    last_pcg_iters = h_solo->iters;
+    return PGO_OK;
+  }
   dev::CgVec V = cg_vec();
   const bool multi = multi_rank();
   dev::GroupPre GP;
@@ -938,8 +1024,18 @@ int pgo_handle::lm_iteration(bool* stop) {
 
   // LM diagonal + preconditioner, then the linear solve
   double t0 = wall_s();
+  PGOC(prepare_system());
+  int k_it = 0;
+  double rel = 0.0;
+  PGOC(pcg(&k_it, &rel));
+  return lm_iteration_tail(stop, R, it0, t0, k_it, rel);
+}
+
+// LM diagonal for the current radius (per problem in a batched handle) + the preconditioner's set-up
+int pgo_handle::prepare_system() {
   hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, (const double*)diag_full, S.n_loc, S.lo, fixed_internal, radius,
-                     opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv);
+                     opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv, (const uint8_t*)fixed_mask, (const int32_t*)prob_of_256,
+                     (const double*)prob_radius);
   PGOC(check_launch("k_prepare"));
   if (grp_B > 1) {
     dev::GroupPrepArgs GA;
@@ -966,23 +1062,26 @@ int pgo_handle::lm_iteration(bool* stop) {
                        chain_pad, chain_len, chain_chunk ? chain_chunk : dev::CHAIN_CHUNK, chain_w, chain_s);
     PGOC(check_launch("k_chain_factor"));
   }
-  int k_it = 0;
-  double rel = 0.0;
-  PGOC(pcg(&k_it, &rel));
+  return PGO_OK;
+}
+
+int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, double t0, int k_it, double rel) {
   total_pcg += k_it;
   R.pcg_iters = k_it;
   R.pcg_rel_residual = rel;
   // model_cost_change = -(J d).(r + J d / 2), d = -S y   ==   y.gs - y.(H y) / 2
-  hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
-  PGOC(check_launch("k_scatter_owned"));
-  PGOC(share_gather_vector(p_full));
-  PGOC(spmv_enqueue(p_full, ap, part[0], 0, nullptr));  // part[0] <- partials of y.(H y)
-  hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs, part[1]);
-  PGOC(check_launch("k_dot"));
-  // candidate x + d and |d|^2
-  double* x_old = poses;
-  hipLaunchKernelGGL(dev::k_candidate, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, x_old, scale, y, cand, part[3]);
-  PGOC(check_launch("k_candidate"));
+  if (!solo) {  // (the one-workgroup solve has done all of this in its epilogue; the gather vector holds y either way)
+    hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
+    PGOC(check_launch("k_scatter_owned"));
+    PGOC(share_gather_vector(p_full));
+    PGOC(spmv_enqueue(p_full, ap, part[0], 0, nullptr));  // part[0] <- partials of y.(H y)
+    hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs, part[1]);
+    PGOC(check_launch("k_dot"));
+    // candidate x + d and |d|^2
+    double* x_old = poses;
+    hipLaunchKernelGGL(dev::k_candidate, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, x_old, scale, y, cand, part[3]);
+    PGOC(check_launch("k_candidate"));
+  }
   double model_sw = 0.0, step2_sw = 0.0;
   if (has_sw) {  // back-substitute the switches (needs y of both endpoints: in the gather vector after the share above)
     const int g_sw = std::min(std::max(1, (S.n_edges_local + dev::WG - 1) / dev::WG), 1024);
@@ -991,8 +1090,14 @@ int pgo_handle::lm_iteration(bool* stop) {
     PGOC(check_launch("k_switch_backsub"));
     PGOC(reduce_to_scal({{part[2], g_sw, 0}, {part[4], g_sw, 0}}, 13));
   }
-  PGOC(reduce_to_scal({{part[1], g_flat, 0}, {part[0], g_spmv, 0}, {part[3], g_flat, 0}}, 0));
-  PGOC(fetch_scal(0, 3));
+  if (solo) {
+    h_scal[0] = h_solo->ydotg;
+    h_scal[1] = h_solo->yHy;
+    h_scal[2] = h_solo->step2;
+  } else {
+    PGOC(reduce_to_scal({{part[1], g_flat, 0}, {part[0], g_spmv, 0}, {part[3], g_flat, 0}}, 0));
+    PGOC(fetch_scal(0, 3));
+  }
   if (has_sw) {
     PGOC(fetch_scal(13, 2));
     model_sw = h_scal[13];
@@ -1442,6 +1547,408 @@ int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   return PGO_OK;
 }
 
+}  // extern "C"
+
+// ====================================================================== batched independent solves
+// the reference's layer managers (METHOD 3/4) are control logic around thousands of small independent
+// ceres::Solve calls -- a copy of the whole graph or a window per candidate layer / edge, plain functor + Huber, the
+// first pose constant, 1-2 LM iterations each (src/simple_layer_manager.cpp:457-622, src/layer_manager.cpp:137-179,
+// 602-654).  A pgo_batch is ONE handle over the block-diagonal union of n such problems: one launch of the fused edge
+// kernel / the assembly kernel / the preconditioner set-up covers all of them, k_pcg_solo solves every problem's linear
+// system in its own workgroup, and the TrustRegionMinimizer state (radius, cost, accept / reject, termination) is kept
+// per problem.  About ten launches per LM iteration for the whole batch, whatever n is.
+struct pgo_batch {
+  std::unique_ptr<pgo_handle> U;
+  int32_t n = 0;
+  std::vector<int32_t> row0, npos, nedge;     // per problem: first row of the union, poses, edges
+  struct State {
+    bool active = true;
+    int iter = 0, prev_success = 1, invalid_run = 0, successful = 0, total_pcg = 0, termination = 0;
+    double cost = 0, initial_cost = 0, radius = 0, decrease_factor = 2, x_norm = 0, gmax = 0, seconds = 0;
+    std::vector<pgo_iter_record> recs;
+  };
+  std::vector<State> st;
+  std::vector<dev::SoloProb> h_prob;
+  dev::SoloProb* d_prob = nullptr;
+  dev::SoloOut* d_out = nullptr;
+  dev::ProbRange* d_range = nullptr;
+  dev::ProbSums* d_sums = nullptr;
+  int32_t* d_accept = nullptr;
+  std::vector<dev::SoloOut> h_out;
+  std::vector<dev::ProbSums> h_sums;
+  std::vector<int32_t> h_accept;
+  std::vector<double> h_radius;
+  bool begun = false;
+
+  int reduce(bool with_cost, bool with_grad, const double* x) {
+    pgo_handle& H = *U;
+    hipLaunchKernelGGL(dev::k_prob_reduce, dim3(n), dim3(dev::WG), 0, H.stream, (const dev::ProbRange*)d_range,
+                       with_cost ? (const double*)H.edge_cost : (const double*)nullptr,
+                       with_grad ? (const double*)H.gs : (const double*)nullptr, (const double*)H.scale, x, H.S.lo, d_sums);
+    PGOC(H.check_launch("k_prob_reduce"));
+    HIPC(hipMemcpyAsync(h_sums.data(), d_sums, (size_t)n * sizeof(dev::ProbSums), hipMemcpyDeviceToHost, H.stream));
+    return H.sync();
+  }
+  int begin();
+  int iterate(bool* all_done);
+};
+
+int pgo_batch::begin() {
+  pgo_handle& H = *U;
+  HIPC(hipSetDevice(H.device));
+  const pgo_options& o = H.opt;
+  for (State& z : st) z = State();
+  // iteration 0: unit scales -> column norms -> Jacobi scaling (per column, so per problem by construction)
+  hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(H.g_rows), dim3(dev::WG), 0, H.stream, H.hd, H.S.n_loc, H.S.lo, -1, 0, H.scale,
+                     (const uint8_t*)H.fixed_mask);
+  PGOC(H.check_launch("k_jacobi_scale"));
+  PGOC(H.eval_enqueue(H.poses, nullptr, 1, true, 0));
+  PGOC(H.assemble_enqueue());
+  if (o.jacobi_scaling) {
+    hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(H.g_rows), dim3(dev::WG), 0, H.stream, H.hd, H.S.n_loc, H.S.lo, -1, 1, H.scale,
+                       (const uint8_t*)H.fixed_mask);
+    PGOC(H.check_launch("k_jacobi_scale"));
+    PGOC(H.assemble_enqueue());
+  }
+  PGOC(reduce(true, true, H.poses));
+  for (int k = 0; k < n; ++k) {
+    State& z = st[k];
+    z.cost = z.initial_cost = h_sums[k].cost;
+    z.gmax = h_sums[k].gmax;
+    z.x_norm = std::sqrt(h_sums[k].xnorm2);
+    z.radius = o.radius0;
+    pgo_iter_record R;
+    memset(&R, 0, sizeof R);
+    R.step_ok = 1;
+    R.cost = z.cost;
+    R.gradient_max_norm = z.gmax;
+    R.radius = z.radius;
+    z.recs.push_back(R);
+    if (!std::isfinite(z.cost)) {  // "Residual and Jacobian evaluation failed" at the initial point
+      z.termination = PGO_TERM_FAILURE;
+      z.active = false;
+    }
+  }
+  begun = true;
+  return PGO_OK;
+}
+
+// one TrustRegionMinimizer iteration of every problem that is still running (same policy as pgo_handle::lm_iteration)
+int pgo_batch::iterate(bool* all_done) {
+  pgo_handle& H = *U;
+  const pgo_options& o = H.opt;
+  const double it0 = wall_s();
+  int n_active = 0;
+  for (int k = 0; k < n; ++k) {
+    State& z = st[k];
+    if (z.active) {
+      if (z.iter >= o.max_iters) z.termination = PGO_TERM_NO_CONVERGENCE;
+      else if (z.prev_success && z.gmax <= o.gtol) z.termination = PGO_TERM_CONVERGENCE_GTOL;
+      else if (z.radius < o.min_radius) z.termination = PGO_TERM_MIN_RADIUS;
+      if (z.termination) z.active = false;
+    }
+    h_prob[k].active = z.active ? 1 : 0;
+    h_radius[k] = z.radius;
+    n_active += z.active;
+  }
+  *all_done = n_active == 0;
+  if (n_active == 0) return PGO_OK;
+  HIPC(hipMemcpyAsync(d_prob, h_prob.data(), (size_t)n * sizeof(dev::SoloProb), hipMemcpyHostToDevice, H.stream));
+  HIPC(hipMemcpyAsync(H.prob_radius, h_radius.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, H.stream));
+  PGOC(H.prepare_system());
+  dev::SoloArgs A;
+  A.A = H.spmv_args(H.p_full, H.ap, H.part[0], 1, nullptr);
+  A.V = H.cg_vec();
+  A.C = H.chain_pre();
+  if (!H.chain_len) A.C.cw = nullptr;
+  A.chain_steps = H.solo_steps;
+  A.scan_levels = H.solo_scan;
+  A.b = H.gs;
+  A.prob = d_prob;
+  A.out = d_out;
+  A.x = H.poses;
+  A.scale = H.scale;
+  A.cand = H.cand;
+  hipLaunchKernelGGL(dev::k_pcg_solo, dim3(n), dim3(dev::SOLO_WG), 0, H.stream, A);
+  PGOC(H.check_launch("k_pcg_solo"));
+  HIPC(hipMemcpyAsync(h_out.data(), d_out, (size_t)n * sizeof(dev::SoloOut), hipMemcpyDeviceToHost, H.stream));
+  // candidate cost of every problem (the rows of idle problems: cand was not written this iteration -- never read below)
+  PGOC(H.eval_enqueue(H.cand, nullptr, 1, false, 0));
+  PGOC(reduce(true, false, H.cand));
+  bool any_accept = false;
+  std::vector<pgo_iter_record> R((size_t)n);
+  for (int k = 0; k < n; ++k) {
+    h_accept[k] = 0;
+    State& z = st[k];
+    if (!z.active) continue;
+    pgo_iter_record& r = R[k];
+    memset(&r, 0, sizeof r);
+    ++z.iter;
+    r.iter = z.iter;
+    const dev::SoloOut& q = h_out[k];
+    z.total_pcg += q.iters;
+    r.pcg_iters = q.iters;
+    r.pcg_rel_residual = q.bb > 0.0 ? std::sqrt(q.rr / q.bb) : 0.0;
+    const double model = q.ydotg - 0.5 * q.yHy;
+    r.gradient_max_norm = z.gmax;
+    if (!std::isfinite(model) || !std::isfinite(q.step2) || !(model > 0.0)) {  // invalid step
+      if (++z.invalid_run >= 5) {
+        z.termination = PGO_TERM_FAILURE;
+        z.active = false;
+        --z.iter;
+        continue;
+      }
+      z.radius /= z.decrease_factor;
+      z.decrease_factor *= 2.0;
+      z.prev_success = 0;
+      r.step_ok = -1;
+      r.cost = z.cost;
+      r.radius = z.radius;
+      z.recs.push_back(r);
+      continue;
+    }
+    z.invalid_run = 0;
+    double cand_cost = h_sums[k].cost;
+    if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    r.step_norm = std::sqrt(q.step2);
+    r.cost_change = z.cost - cand_cost;
+    if (r.step_norm <= o.ptol * (z.x_norm + o.ptol) || std::fabs(r.cost_change) <= o.ftol * z.cost) {
+      z.termination = (r.step_norm <= o.ptol * (z.x_norm + o.ptol)) ? PGO_TERM_CONVERGENCE_PTOL : PGO_TERM_CONVERGENCE_FTOL;
+      z.active = false;
+      r.cost = z.cost;
+      r.radius = z.radius;
+      z.recs.push_back(r);
+      continue;
+    }
+    const double rho = (cand_cost >= std::numeric_limits<double>::max()) ? -std::numeric_limits<double>::max() : r.cost_change / model;
+    r.relative_decrease = rho;
+    if (rho > o.min_relative_decrease) {
+      h_accept[k] = 1;
+      any_accept = true;
+      const double t = 2.0 * rho - 1.0;
+      z.radius = std::min(o.max_radius, z.radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
+      z.decrease_factor = 2.0;
+      z.prev_success = 1;
+      ++z.successful;
+      r.step_ok = 1;
+    } else {
+      z.radius /= z.decrease_factor;
+      z.decrease_factor *= 2.0;
+      z.prev_success = 0;
+      r.step_ok = 0;
+      r.cost = cand_cost;
+      r.radius = z.radius;
+      z.recs.push_back(r);
+    }
+  }
+  if (any_accept) {
+    HIPC(hipMemcpyAsync(d_accept, h_accept.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, H.stream));
+    hipLaunchKernelGGL(dev::k_accept_rows, dim3(H.g_flat), dim3(dev::WG), 0, H.stream, H.S.n_loc, H.S.lo, (const int32_t*)H.prob_of_256,
+                       (const int32_t*)d_accept, (const double*)H.cand, H.poses);
+    PGOC(H.check_launch("k_accept_rows"));
+    // re-linearise everything: the problems that did not move reproduce their records and blocks bit for bit
+    PGOC(H.eval_enqueue(H.poses, nullptr, 1, true, 0));
+    PGOC(H.assemble_enqueue());
+    PGOC(reduce(true, true, H.poses));
+    for (int k = 0; k < n; ++k) {
+      if (!h_accept[k]) continue;
+      State& z = st[k];
+      pgo_iter_record& r = R[k];
+      if (!std::isfinite(h_sums[k].cost)) {  // non-finite Jacobian at an accepted point (the asin' singularity)
+        z.termination = PGO_TERM_FAILURE;
+        z.active = false;
+      } else {
+        z.cost = h_sums[k].cost;
+        z.gmax = h_sums[k].gmax;
+        z.x_norm = std::sqrt(h_sums[k].xnorm2);
+      }
+      r.cost = z.cost;
+      r.gradient_max_norm = z.gmax;
+      r.radius = z.radius;
+      z.recs.push_back(r);
+    }
+  }
+  const double dt = wall_s() - it0;
+  for (int k = 0; k < n; ++k)
+    if (h_prob[k].active) {
+      st[k].seconds += dt;
+      if (!st[k].recs.empty()) st[k].recs.back().seconds = dt;
+    }
+  return PGO_OK;
+}
+
+extern "C" {
+
+int pgo_batch_create(pgo_batch_t** out, int32_t n, const pgo_graph* const* graphs, const pgo_options* opt, int device) {
+  if (!out || n <= 0 || !graphs) return fail(PGO_ERR_INVALID_ARG, "pgo_batch_create: bad argument");
+  pgo_options o;
+  if (opt) o = *opt;
+  else pgo_options_default(&o);
+  if (o.method != 0 && o.method != 1) return fail(PGO_ERR_UNSUPPORTED, "pgo_batch: METHOD 0 and 1 only");
+  if (o.info_weighting) return fail(PGO_ERR_UNSUPPORTED, "pgo_batch: info_weighting is not supported");
+  if (o.pcg_block_poses > 1) return fail(PGO_ERR_UNSUPPORTED, "pgo_batch: the chain or the 3x3 block-Jacobi preconditioner only");
+  PGOC(require_device(device));
+  std::unique_ptr<pgo_batch> B(new pgo_batch);
+  B->n = n;
+  B->row0.resize(n);
+  B->npos.resize(n);
+  B->nedge.resize(n);
+  int64_t rows = 0, edges = 0;
+  int32_t big = 0;
+  for (int32_t k = 0; k < n; ++k) {
+    if (!graphs[k] || graphs[k]->g.n_poses() <= 0) return fail(PGO_ERR_INVALID_ARG, "pgo_batch_create: problem " + std::to_string(k) + " is empty");
+    const pgo::Graph& G = graphs[k]->g;
+    if (o.fixed_pose >= G.n_poses()) return fail(PGO_ERR_INVALID_ARG, "pgo_batch_create: fixed_pose out of range in problem " + std::to_string(k));
+    B->row0[k] = (int32_t)rows;
+    B->npos[k] = G.n_poses();
+    B->nedge[k] = G.n_edges();
+    rows += ((int64_t)G.n_poses() + 255) / 256 * 256;   // every problem starts on a 256-row boundary
+    edges += G.n_edges();
+    if (G.n_poses() > graphs[big]->g.n_poses()) big = k;
+    if (rows > (int64_t)1 << 30 || edges > (int64_t)1 << 30) return fail(PGO_ERR_INVALID_ARG, "pgo_batch_create: batch too large");
+  }
+  // the union: poses (padding rows at the origin, constant), edges shifted to the union's numbering
+  std::vector<double> poses((size_t)3 * rows, 0.0), meas((size_t)3 * edges);
+  std::vector<int32_t> ia((size_t)edges), ib((size_t)edges);
+  std::vector<uint8_t> kind((size_t)edges);
+  std::unique_ptr<pgo_handle> H(new pgo_handle);
+  H->fixed_mask_h.assign((size_t)rows, 1);
+  int64_t eo = 0;
+  for (int32_t k = 0; k < n; ++k) {
+    const pgo::Graph& G = graphs[k]->g;
+    const int32_t r0 = B->row0[k];
+    memcpy(&poses[(size_t)3 * r0], G.pose.data(), (size_t)3 * G.n_poses() * sizeof(double));
+    for (int32_t i = 0; i < G.n_poses(); ++i) H->fixed_mask_h[(size_t)r0 + i] = (i == o.fixed_pose) ? 1 : 0;
+    for (int32_t e = 0; e < G.n_edges(); ++e) {
+      if (G.ea[e] < 0 || G.ea[e] >= G.n_poses() || G.eb[e] < 0 || G.eb[e] >= G.n_poses() || G.ea[e] == G.eb[e])
+        return fail(PGO_ERR_INVALID_ARG, "pgo_batch_create: problem " + std::to_string(k) + ", edge " + std::to_string(e) + ": bad endpoints");
+      ia[(size_t)eo + e] = r0 + G.ea[e];
+      ib[(size_t)eo + e] = r0 + G.eb[e];
+      kind[(size_t)eo + e] = G.kind[e];
+    }
+    if (G.n_edges()) memcpy(&meas[(size_t)3 * eo], G.meas.data(), (size_t)3 * G.n_edges() * sizeof(double));
+    if (k > 0) H->tile_breaks_h.push_back(r0);
+    eo += G.n_edges();
+  }
+  // one preconditioner for the whole batch: what the library would choose for the largest problem alone (the dense
+  // pose-block form has no one-workgroup kernel: 64-pose chain segments stand in for it)
+  const pgo::Graph& GB = graphs[big]->g;
+  int chain = pgo::resolve_chain_len(o.pcg_chain_len, o.pcg_block_poses, GB.n_poses(), GB.n_edges(), GB.ea.data(), GB.eb.data());
+  if (chain == 0 && o.pcg_block_poses != 1) chain = 64;
+  o.pcg_chain_len = chain;
+  o.pcg_block_poses = 1;
+  o.fixed_pose = -1;       // the mask carries one anchor per problem
+  o.pose_ordering = 0;
+  H->opt = o;
+  H->comm = nullptr;
+  H->device = device;
+  H->batch_mode = true;
+  PGOC(H->create((int32_t)rows, poses.data(), (int32_t)edges, ia.data(), ib.data(), meas.data(), nullptr, kind.data()));
+  // per-problem ranges in the handle's local edge order (sorted by smaller endpoint => contiguous per problem) and tiles
+  std::vector<dev::ProbRange> rng((size_t)n);
+  std::vector<int32_t> p256((size_t)(rows / 256));
+  B->h_prob.resize(n);
+  {
+    const pgo::ShardStructure& S = H->S;
+    int32_t e = 0, t = 0;
+    for (int32_t k = 0; k < n; ++k) {
+      const int32_t r0 = B->row0[k], r1 = (k + 1 < n) ? B->row0[k + 1] : (int32_t)rows;
+      rng[k].row0 = r0;
+      rng[k].nrows = B->npos[k];
+      rng[k].e0 = e;
+      while (e < S.n_edges_local && std::min(S.ia[e], S.ib[e]) < r1) ++e;
+      rng[k].e1 = e;
+      while (t < S.n_tiles() && S.tile_row[t] < r0) ++t;
+      if (t >= S.n_tiles() || S.tile_row[t] != r0) return fail(PGO_ERR_HIP, "pgo_batch_create: internal: tile boundaries");
+      const int32_t t0 = t;
+      while (t < S.n_tiles() && S.tile_row[t] < r1) ++t;
+      dev::SoloProb& P = B->h_prob[k];
+      P.row0 = r0;
+      P.nrows = B->npos[k];
+      P.tile0 = t0;
+      P.ntiles = t - t0;
+      P.active = 1;
+      P.max_it = std::max(0, o.pcg_max_iters);
+      P.rtol = o.pcg_rtol;
+      for (int32_t b = r0 / 256; b < r1 / 256; ++b) p256[b] = k;
+    }
+  }
+  PGOC(H->dalloc(&H->prob_of_256, (int64_t)p256.size()));
+  PGOC(H->upload(H->prob_of_256, p256));
+  PGOC(H->dalloc(&H->prob_radius, n));
+  PGOC(H->dalloc(&B->d_prob, n));
+  PGOC(H->dalloc(&B->d_out, n));
+  PGOC(H->dalloc(&B->d_range, n));
+  PGOC(H->dalloc(&B->d_sums, n));
+  PGOC(H->dalloc(&B->d_accept, n));
+  PGOC(H->upload(B->d_range, rng));
+  PGOC(H->sync());  // rng / p256 die with this scope
+  B->h_out.resize(n);
+  B->h_sums.resize(n);
+  B->h_accept.assign(n, 0);
+  B->h_radius.assign(n, 0.0);
+  B->st.resize(n);
+  B->U = std::move(H);
+  *out = B.release();
+  return PGO_OK;
+}
+
+void pgo_batch_destroy(pgo_batch_t* b) { delete b; }
+
+int pgo_batch_solve(pgo_batch_t* b, pgo_summary* summaries) {
+  if (!b) return fail(PGO_ERR_INVALID_ARG, "pgo_batch_solve: null");
+  PGOC(b->begin());
+  bool done = false;
+  while (!done) PGOC(b->iterate(&done));
+  if (summaries)
+    for (int32_t k = 0; k < b->n; ++k) {
+      const pgo_batch::State& z = b->st[k];
+      pgo_summary& s = summaries[k];
+      memset(&s, 0, sizeof s);
+      s.termination = z.termination;
+      s.iterations = z.iter;
+      s.successful_steps = z.successful;
+      s.total_pcg_iters = z.total_pcg;
+      s.initial_cost = z.initial_cost;
+      s.final_cost = z.cost;
+      s.seconds_total = z.seconds;
+    }
+  return PGO_OK;
+}
+
+int32_t pgo_batch_size(const pgo_batch_t* b) { return b ? b->n : 0; }
+
+int pgo_batch_get_poses(pgo_batch_t* b, int32_t k, double* out) {
+  if (!b || !out || k < 0 || k >= b->n) return fail(PGO_ERR_INVALID_ARG, "pgo_batch_get_poses: bad argument");
+  pgo_handle& H = *b->U;
+  HIPC(hipSetDevice(H.device));
+  HIPC(hipMemcpyAsync(out, H.poses + 3 * (int64_t)b->row0[k], (size_t)3 * b->npos[k] * sizeof(double), hipMemcpyDeviceToHost, H.stream));
+  return H.sync();
+}
+
+int pgo_batch_set_poses(pgo_batch_t* b, int32_t k, const double* poses) {
+  if (!b || !poses || k < 0 || k >= b->n) return fail(PGO_ERR_INVALID_ARG, "pgo_batch_set_poses: bad argument");
+  pgo_handle& H = *b->U;
+  HIPC(hipSetDevice(H.device));
+  HIPC(hipMemcpyAsync(H.poses + 3 * (int64_t)b->row0[k], poses, (size_t)3 * b->npos[k] * sizeof(double), hipMemcpyHostToDevice, H.stream));
+  b->begun = false;
+  return H.sync();
+}
+
+int32_t pgo_batch_num_iter_records(const pgo_batch_t* b, int32_t k) {
+  return (b && k >= 0 && k < b->n) ? (int32_t)b->st[k].recs.size() : 0;
+}
+int pgo_batch_get_iter_records(const pgo_batch_t* b, int32_t k, pgo_iter_record* out, int32_t cap) {
+  if (!b || !out || k < 0 || k >= b->n) return fail(PGO_ERR_INVALID_ARG, "pgo_batch_get_iter_records: bad argument");
+  const int32_t m = std::min<int32_t>(cap, (int32_t)b->st[k].recs.size());
+  memcpy(out, b->st[k].recs.data(), (size_t)m * sizeof(pgo_iter_record));
+  return PGO_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 int32_t pgo_num_iter_records(const pgo_t* h) { return h ? (int32_t)h->recs.size() : 0; }
 int pgo_get_iter_records(const pgo_t* h, pgo_iter_record* out, int32_t cap) {
   if (!h || !out) return fail(PGO_ERR_INVALID_ARG, "pgo_get_iter_records: null");
@@ -1457,7 +1964,7 @@ int pgo_debug_normal_eq(pgo_t* h, double* g_out, double* hdiag_out) {
   HIPC(hipSetDevice(h->device));
   h->lm_active = false;
   hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(h->g_rows), dim3(dev::WG), 0, h->stream, h->hd, h->S.n_loc, h->S.lo,
-                     h->fixed_internal, 0, h->scale);
+                     h->fixed_internal, 0, h->scale, (const uint8_t*)h->fixed_mask);
   PGOC(h->check_launch("k_jacobi_scale"));
   int st = h->linearize(false);
   h->lin_valid = false;

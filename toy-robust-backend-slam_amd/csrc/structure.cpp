@@ -136,7 +136,8 @@ static void build_halo_lists(int32_t E, const int32_t* ia, const int32_t* ib, Sh
 }
 
 int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t* ib, const double* meas,
-                          const uint8_t* kind, int method, int world, int rank, int row_align, ShardStructure* S) {
+                          const uint8_t* kind, int method, int world, int rank, int row_align, ShardStructure* S,
+                          const std::vector<int32_t>* tile_breaks) {
   if (N <= 0 || E < 0 || world < 1 || rank < 0 || rank >= world || row_align < 1)
     return fail(PGO_ERR_INVALID_ARG, "build_shard_structure: bad sizes");
   for (int32_t e = 0; e < E; ++e) {
@@ -246,12 +247,15 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
   S->tile_row.clear();
   S->tile_row.push_back(0);
   int32_t row = 0;
+  size_t nb = 0;  // next tile break (global rows, ascending): a batched handle starts a tile at every problem start
   while (row < S->n_loc) {
     int32_t begin = row;
     int64_t inc0 = ptr[row];
+    while (tile_breaks && nb < tile_breaks->size() && (*tile_breaks)[nb] <= lo + row) ++nb;
+    const int32_t stop = (tile_breaks && nb < tile_breaks->size()) ? (*tile_breaks)[nb] - lo : S->n_loc;
     // at least one row per tile; more while their incidences fit one chunk
     ++row;
-    while (row < S->n_loc && ptr[row + 1] - inc0 <= TILE_INC && row - begin < TILE_INC) ++row;
+    while (row < S->n_loc && row < stop && ptr[row + 1] - inc0 <= TILE_INC && row - begin < TILE_INC) ++row;
     S->tile_row.push_back(row);
   }
   if (S->n_loc == 0) S->tile_row.assign(1, 0);
