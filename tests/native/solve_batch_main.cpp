@@ -1,4 +1,4 @@
-// pgo::SolveBatch through the C++ mirror of the reference interface, shaped like the reference's layer managers use
+// pgo::SolveBatch (one batched handle, pgo_batch_*) through the C++ mirror of the reference interface, shaped like the reference's layer managers use
 // Ceres (src/simple_layer_manager.cpp:457-497): per layer a COPY of all poses, a ceres::Problem with every odometry edge +
 // the layer's loop edges (plain OdometryResidue, shared Huber), pose 0 constant, local_iters = 2 iterations.
 // Built and run by tests/test_gpu_parity.py::test_host_solve_batch (needs a GPU).
@@ -60,15 +60,17 @@ int main(int argc, char** argv) {
   for (int l = 0; l < n_layers; ++l) {
     pgo::Solver::Summary s1;
     pgo::Solve(options, single[l].problem.get(), &s1);
-    if (s1.s.final_cost != sums[l].s.final_cost || s1.s.iterations != sums[l].s.iterations) {
+    // the batched handle sums its dot products per workgroup, an ordinary handle per tile: equal up to rounding
+    if (std::fabs(s1.s.final_cost - sums[l].s.final_cost) > 1e-10 * s1.s.final_cost || s1.s.iterations != sums[l].s.iterations) {
       fprintf(stderr, "layer %d: summaries differ (%.17g vs %.17g)\n", l, s1.s.final_cost, sums[l].s.final_cost);
       return 1;
     }
     for (size_t i = 0; i < g2o.nNodes.size(); ++i)
-      if (memcmp(single[l].poses[i], batch[l].poses[i], 3 * sizeof(double)) != 0) {
-        fprintf(stderr, "layer %d pose %zu differs\n", l, i);
-        return 1;
-      }
+      for (int c = 0; c < 3; ++c)
+        if (std::fabs(single[l].poses[i][c] - batch[l].poses[i][c]) > 1e-9) {
+          fprintf(stderr, "layer %d pose %zu differs (%.3e)\n", l, i, single[l].poses[i][c] - batch[l].poses[i][c]);
+          return 1;
+        }
     if (!(sums[l].s.final_cost < sums[l].s.initial_cost)) return 1;
     printf("layer %d: edges %zu  cost %.6f -> %.6f  (%d iterations)\n", l, single[l].edges.size(), sums[l].s.initial_cost,
            sums[l].s.final_cost, sums[l].s.iterations);

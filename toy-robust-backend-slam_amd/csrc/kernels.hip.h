@@ -609,6 +609,17 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
 }
 
 // ------------------------------------------------------------------- K3
+struct CgState {       // lives in device memory
+  double rz[2];        // r.z, double-buffered by iteration parity
+  double bb;           // b.b
+  double rr;           // r.r after the latest update
+  double tol2;         // (rtol^2) b.b
+  int32_t done;
+  int32_t iters;
+  int32_t pending;     // fused-update loop (k_spmv MODE 5): an iteration's r.z / r.r partials wait to be booked
+  int32_t _pad;
+};
+
 struct SpmvArgs {
   const int32_t* inc_ptr;
   const int32_t* inc_col;    // global pose position of the column block
@@ -627,6 +638,16 @@ struct SpmvArgs {
   double* y;                 // [n_loc x 3]
   double* dot_part;          // [gridDim.x] partial of p_owned . y
   const int32_t* done;       // skip when *done != 0 (nullptr: never)
+  // MODE 5 only (small graphs, one rank): the direction update p = z + beta p of the PREVIOUS iteration is applied on
+  // the fly -- gathered as z[col] + beta p_old[col], written for the tile's own rows to p_new -- so that a PCG iteration
+  // is two launches instead of three.  A.p is p_old; beta and the convergence decision come from the r.z / r.r partials
+  // of the previous k_cg_update1, re-summed by every workgroup; workgroup 0 books them in st (once: st->pending).
+  const double* z;           // [n_loc x 3]
+  double* p_new;             // gather vector of this iteration (the other buffer of the pair)
+  const double* part_rz;
+  const double* part_rr;
+  int32_t n_rz, n_rr, parity;  // parity of the iteration whose partials these are
+  CgState* st;
 };
 
 // Algorithmic bytes: 76 per off-diagonal block (72 value + 4 column index) + per row
@@ -643,6 +664,17 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   __shared__ double red[8];
   const int tid = threadIdx.x;
   if (A.done && *A.done) return;
+  double beta = 0.0;
+  // gathered search direction of pose `col` (global index)
+  auto load_p = [&](int64_t col, double& p0, double& p1, double& p2) {
+    gather3(A.p, col, p0, p1, p2);
+    if (MODE == 5) {
+      const double* zc = A.z + 3 * (col - A.lo);
+      p0 = zc[0] + beta * p0;
+      p1 = zc[1] + beta * p1;
+      p2 = zc[2] + beta * p2;
+    }
+  };
   double dot = 0.0;
   int buf = 0;
   const int64_t n = A.n_loc;
@@ -658,6 +690,20 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   if (t < xr.end) {
     d = A.tile_desc[t];
     if (d.w <= WG && tid < d.w) col_pf = ld_stream(A.inc_col + d.z + tid);
+  }
+  if (MODE == 5) {  // (after the first tile's loads are on their way: independent of them)
+    const double rz_new = sum_partials_bcast(A.part_rz, A.n_rz, red);
+    const double rr = sum_partials_bcast(A.part_rr, A.n_rr, red);
+    const double rz_old = A.st->rz[A.parity], tol2 = A.st->tol2;
+    if (blockIdx.x == 0 && tid == 0 && A.st->pending) {  // book the previous iteration (k_cg_update2's scalar part)
+      A.st->rz[A.parity ^ 1] = rz_new;
+      A.st->rr = rr;
+      A.st->iters += 1;
+      A.st->pending = 0;
+      if (rr <= tol2) A.st->done = 1;
+    }
+    if (rr <= tol2 && A.st->iters + A.st->pending > 0) return;  // converged (same decision everywhere; never before iteration 1)
+    beta = rz_new / rz_old;
   }
   for (; t < xr.end; t += xr.step) {
     const int r0 = d.x, nrows = d.y, q0 = d.z, nq = d.w;
@@ -682,10 +728,8 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         h1 = ld_stream(A.hd + ((int64_t)i1 * n + row));
         h2 = ld_stream(A.hd + ((int64_t)i2 * n + row));
         if (A.with_d2) dd = ld_stream(A.d2 + (3 * (int64_t)row + a));
-        const double* pr = A.p + PS * (int64_t)(A.lo + row);
-        pr0 = pr[0];
-        pr1 = pr[1];
-        pr2 = pr[2];
+        load_p((int64_t)A.lo + row, pr0, pr1, pr2);
+        if (MODE == 5) A.p_new[PS * (int64_t)(A.lo + row) + a] = (a == 0) ? pr0 : (a == 1 ? pr1 : pr2);
       }
       const int q = q0 + tid;
       const bool lane_on = q < q1;
@@ -696,7 +740,7 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         if (MODE == 1 || MODE == 3) {
           p0 = (double)col; p1 = p0 + 1.0; p2 = p0 + 2.0;
         } else {
-          gather3(A.p, col, p0, p1, p2);
+          load_p(col, p0, p1, p2);
         }
         if (MODE != 2 && MODE != 3) {
           if (A.nt) hoff_load_nt(A.hoff, q, h);
@@ -730,7 +774,9 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
         const int lo2 = A.inc_ptr[row2] - q0, hi2 = A.inc_ptr[row2 + 1] - q0;
         double s = 0.0;
         for (int j = lo2; j < hi2; ++j) s += scr[buf][a2][j];
-        const double* pr = A.p + PS * (int64_t)(A.lo + row2);
+        double pr[3];
+        load_p((int64_t)A.lo + row2, pr[0], pr[1], pr[2]);
+        if (MODE == 5) A.p_new[PS * (int64_t)(A.lo + row2) + a2] = pr[a2];
         const int i1 = (a2 == 0) ? 1 : (a2 == 1 ? 3 : 4), i2 = (a2 == 2) ? 5 : (a2 == 1 ? 4 : 2);
         double dg = A.hd[(int64_t)a2 * n + row2] * pr[0];
         dg += A.hd[(int64_t)i1 * n + row2] * pr[1];
@@ -754,7 +800,7 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
             scr[buf][2][tid] = 0.0;
           } else {
             double p0, p1, p2, h[9];
-            gather3(A.p, col, p0, p1, p2);
+            load_p(col, p0, p1, p2);
             hoff_load(A.hoff, q, h);
             scr[buf][0][tid] = h[0] * p0 + h[1] * p1 + h[2] * p2;
             scr[buf][1][tid] = h[3] * p0 + h[4] * p1 + h[5] * p2;
@@ -772,7 +818,9 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
       }
       if (tid < 3) {
         const int a = tid, row = r0;
-        const double* pr = A.p + PS * (int64_t)(A.lo + row);
+        double pr[3];
+        load_p((int64_t)A.lo + row, pr[0], pr[1], pr[2]);
+        if (MODE == 5) A.p_new[PS * (int64_t)(A.lo + row) + a] = pr[a];
         const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
         double dg = A.hd[(int64_t)a * n + row] * pr[0];
         dg += A.hd[(int64_t)i1 * n + row] * pr[1];
@@ -936,14 +984,6 @@ __global__ __launch_bounds__(WG) void k_finalize(FinArgs A) {
 }
 
 // ------------------------------------------------------------------- K5
-struct CgState {       // lives in device memory
-  double rz[2];        // r.z, double-buffered by iteration parity
-  double bb;           // b.b
-  double rr;           // r.r after the latest update
-  double tol2;         // (rtol^2) b.b
-  int32_t done;
-  int32_t iters;
-};
 
 struct CgVec {
   int32_t n_loc;
@@ -955,6 +995,8 @@ struct CgVec {
   double* ap;          // A p
   double* p;           // search direction, GLOBAL indexing (gathered by K3)
   CgState* st;
+  int32_t fused;       // 1: the direction update is fused into the next k_spmv (MODE 5); update1 then flags its partials pending
+  int32_t _pad;
 };
 
 __device__ __forceinline__ void minv_apply(const double* __restrict__ minv, int64_t n, int row, double r0, double r1,
@@ -996,12 +1038,13 @@ __global__ __launch_bounds__(WG) void k_cg_init(CgVec V, const double* __restric
 __global__ void k_cg_init_fin(CgState* st, const double* __restrict__ scal, double rtol) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     st->rz[0] = scal[0];
-    st->rz[1] = 0.0;
+    st->rz[1] = scal[0];   // (finite beta for the fused loop's first, no-op direction update)
     st->bb = scal[1];
     st->rr = scal[1];
     st->tol2 = rtol * rtol * scal[1];
     st->done = (scal[1] == 0.0) ? 1 : 0;
     st->iters = 0;
+    st->pending = 0;
   }
 }
 
@@ -1040,6 +1083,24 @@ __global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, const do
   if (threadIdx.x == 0) {
     part_rz[blockIdx.x] = rz;
     part_rr[blockIdx.x] = rr;
+  }
+  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) V.st->pending = 1;
+}
+
+// End of a slice of fused-update iterations (k_spmv MODE 5): book the last iteration's partials so that the host sees
+// its iteration count, residual and convergence flag.  One workgroup.
+__global__ __launch_bounds__(WG) void k_cg_book(CgState* st, int parity, const double* __restrict__ part_rz, int n_rz,
+                                                const double* __restrict__ part_rr, int n_rr) {
+  __shared__ double red[8];
+  if (st->done || !st->pending) return;
+  const double rz_new = sum_partials_bcast(part_rz, n_rz, red);
+  const double rr = sum_partials_bcast(part_rr, n_rr, red);
+  if (threadIdx.x == 0) {
+    st->rz[parity ^ 1] = rz_new;
+    st->rr = rr;
+    st->iters += 1;
+    st->pending = 0;
+    if (rr <= st->tol2) st->done = 1;
   }
 }
 
@@ -1247,6 +1308,7 @@ __global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int pa
     part_rz[blockIdx.x] = rz;
     part_rr[blockIdx.x] = rr;
   }
+  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) V.st->pending = 1;
 }
 
 // ------------------------------------------------- chain (block-tridiagonal) preconditioner
@@ -1659,6 +1721,7 @@ __global__ __launch_bounds__(WG) void k_cg_update1_c(CgVec V, ChainPre C, int pa
     part_rz[blockIdx.x] = rz;
     part_rr[blockIdx.x] = rr;
   }
+  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) V.st->pending = 1;
 }
 
 // ------------------------------------------------- chain preconditioner, lean apply (segments of <= 64 * CH rows)
@@ -1837,11 +1900,21 @@ __device__ __forceinline__ void chain_apply_lean(const double (&W)[CH][9], const
 // PCG start-up, lean chain apply: r = b, z = M^-1 r, y = 0, p = z; partials of r.z and b.b.  One wavefront per tile of
 // 64 * CH rows, tiles dealt round-robin over all waves of the grid.  FULL tiles (all but possibly the last) run without
 // per-element predicates: every load of the tile is issued before the first use.
-template <int CH>
-__global__ __launch_bounds__(WG) void k_cg_init_cl(CgVec V, ChainPre C, int n_steps, const double* __restrict__ b,
+// NW = wavefronts per workgroup: 4 on large graphs; 1 on small ones, where four 74-KB tiles behind ONE compute unit's L1
+// took 3.9 us to load (INTEL, 5 tiles) and a workgroup per tile spreads them over the chip.
+template <int NW>
+__device__ __forceinline__ double block_sum_nw(double v, double* sh) {
+  if constexpr (NW == 4) {
+    return block_sum_bcast(v, sh);
+  } else {
+    return __shfl(wave_sum(v), 0, 64);
+  }
+}
+template <int CH, int NW>
+__global__ __launch_bounds__(64 * NW) void k_cg_init_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, const double* __restrict__ b,
                                                    double* __restrict__ part_rz, double* __restrict__ part_bb) {
   constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
-  __shared__ double tile[4][64 * STRIDE];
+  __shared__ double tile[NW][64 * STRIDE];
   __shared__ double red[8];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   double* buf = tile[wave];
@@ -1853,7 +1926,7 @@ __global__ __launch_bounds__(WG) void k_cg_init_cl(CgVec V, ChainPre C, int n_st
   double* __restrict__ vp = V.p + 3 * (int64_t)V.lo;
   double rz = 0.0, bb = 0.0;
   const int64_t n_tiles = ((int64_t)V.n_loc + TILE - 1) / TILE;
-  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n_tiles; t += (int64_t)gridDim.x * 4) {
+  for (int64_t t = (int64_t)blockIdx.x * NW + wave; t < n_tiles; t += (int64_t)gridDim.x * NW) {
     const int64_t wbase = t * TILE, f0 = 3 * wbase;   // uniform: plane / vector bases stay scalar, lane offsets 32-bit
     const unsigned lim = (unsigned)(n3 - f0 < 3 * TILE ? n3 - f0 : 3 * TILE);
     const double* cw_tile = C.cw + wbase;
@@ -1869,7 +1942,11 @@ __global__ __launch_bounds__(WG) void k_cg_init_cl(CgVec V, ChainPre C, int n_st
       for (int j = 0; j < NV; ++j) rv[j] = bt[lane + 64u * j];
     } else {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) rv[j] = (lane + 64u * j) < lim ? bt[lane + 64u * j] : 0.0;
+      for (int j = 0; j < NV; ++j) {
+        const unsigned e = lane + 64u * j;
+        const double v = bt[e < lim ? e : 0u];   // clamped address: no load behind a branch
+        rv[j] = e < lim ? v : 0.0;
+      }
     }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -1877,7 +1954,7 @@ __global__ __launch_bounds__(WG) void k_cg_init_cl(CgVec V, ChainPre C, int n_st
       buf[e + e / (3 * CH)] = rv[j];
     }
     wave_lds_sync();
-    chain_apply_lean<CH>(W, C.cs + wbase, np, lane, ch, n_steps);
+    chain_apply_lean<CH>(W, C.cs + wbase, np, lane, ch, n_steps, scan_levels);
     wave_lds_sync();
     double* yt = vy + f0;
     double* rt = vr + f0;
@@ -1898,8 +1975,8 @@ __global__ __launch_bounds__(WG) void k_cg_init_cl(CgVec V, ChainPre C, int n_st
     }
     wave_lds_sync();
   }
-  rz = block_sum_bcast(rz, red);
-  bb = block_sum_bcast(bb, red);
+  rz = block_sum_nw<NW>(rz, red);
+  bb = block_sum_nw<NW>(bb, red);
   if (tid == 0) {
     part_rz[blockIdx.x] = rz;
     part_bb[blockIdx.x] = bb;
@@ -1907,17 +1984,36 @@ __global__ __launch_bounds__(WG) void k_cg_init_cl(CgVec V, ChainPre C, int n_st
 }
 
 // x += alpha p ; r -= alpha A p ; z = M^-1 r (lean chain apply) ; partials of r.z and r.r
-template <int CH>
-__global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n_steps, int parity,
+#ifdef PGO_PHASE_TIMING
+__device__ unsigned long long g_phase_t[16];
+#define PGO_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_t[k] = wall_clock64(); } while (0)
+#else
+#define PGO_T(k) do { } while (0)
+#endif
+template <int CH, int NW>
+__global__ __launch_bounds__(64 * NW) void k_cg_update1_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, int parity,
                                                       const double* __restrict__ part_pap, int n_pap,
                                                       double* __restrict__ part_rz, double* __restrict__ part_rr) {
   constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
-  __shared__ double tile[4][64 * STRIDE];
+  __shared__ double tile[NW][64 * STRIDE];
   __shared__ double red[8];
-  if (V.st->done) return;
+  PGO_T(0);
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const double pap = sum_partials_bcast(part_pap, n_pap, red);
-  const double alpha = V.st->rz[parity] / pap;
+  double alpha = 0.0, pap_part = 0.0;
+  if constexpr (NW == 4) {
+    if (V.st->done) return;
+    const double pap = sum_partials_bcast(part_pap, n_pap, red);
+    alpha = V.st->rz[parity] / pap;
+  } else {
+    // small graphs: the flag, r.z and the partials leave together (one round trip instead of three); the sum itself
+    // waits until the tile's own loads have been issued
+    const int dn = V.st->done;
+    alpha = V.st->rz[parity];
+    for (int i = threadIdx.x; i < n_pap; i += 64) pap_part += part_pap[i];
+    if (dn) return;
+  }
+  PGO_T(1);
+  PGO_T(2);
   double* buf = tile[wave];
   double* ch = buf + lane * STRIDE;
   const int64_t n3 = 3 * (int64_t)V.n_loc, np = C.n_pad;
@@ -1928,7 +2024,7 @@ __global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n
   const double* __restrict__ pown = V.p + 3 * (int64_t)V.lo;
   double rz = 0.0, rr = 0.0;
   const int64_t n_tiles = ((int64_t)V.n_loc + TILE - 1) / TILE;
-  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n_tiles; t += (int64_t)gridDim.x * 4) {
+  for (int64_t t = (int64_t)blockIdx.x * NW + wave; t < n_tiles; t += (int64_t)gridDim.x * NW) {
     const int64_t wbase = t * TILE, f0 = 3 * wbase;   // uniform: plane / vector bases stay scalar, lane offsets 32-bit
     const unsigned lim = (unsigned)(n3 - f0 < 3 * TILE ? n3 - f0 : 3 * TILE);
     const bool full = lim == 3u * TILE;
@@ -1953,6 +2049,9 @@ __global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n
         yv[j] = ld_stream(yt + e);
         pv[j] = pt[e];
       }
+      if constexpr (NW == 1) {
+        if (t == (int64_t)blockIdx.x) alpha = alpha / block_sum_nw<NW>(pap_part, red);  // first tile of this wave
+      }
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         rv[j] -= alpha * av[j];
@@ -1965,16 +2064,31 @@ __global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n
         st_stream(yt + e, yv[j]);
       }
     } else {
+      // the last, partial tile: the same batched loads from clamped addresses (element 0 of the tile stands in for the
+      // elements past the end), values masked, stores predicated -- no load sits behind a branch (on the small graphs this
+      // tile is a fifth of the kernel: INTEL 13.9 us per launch with per-element branches and their waits)
+      double av[NV], pv[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const unsigned e = lane + 64u * j, ec = e < lim ? e : 0u;
+        rv[j] = rt[ec];
+        av[j] = at[ec];
+        yv[j] = yt[ec];
+        pv[j] = pt[ec];
+      }
+      if constexpr (NW == 1) {
+        if (t == (int64_t)blockIdx.x) alpha = alpha / block_sum_nw<NW>(pap_part, red);  // first tile of this wave
+      }
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const unsigned e = lane + 64u * j;
-        double r = 0.0;
-        if (e < lim) {
-          yt[e] += alpha * pt[e];
-          r = rt[e] - alpha * at[e];
-          rt[e] = r;
+        const bool ok = e < lim;
+        rv[j] = ok ? rv[j] - alpha * av[j] : 0.0;
+        yv[j] += alpha * pv[j];
+        if (ok) {
+          rt[e] = rv[j];
+          yt[e] = yv[j];
         }
-        rv[j] = r;
       }
     }
 #pragma unroll
@@ -1984,8 +2098,10 @@ __global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n
       buf[e + e / (3 * CH)] = rv[j];
     }
     wave_lds_sync();
-    chain_apply_lean<CH>(W, C.cs + wbase, np, lane, ch, n_steps);
+    PGO_T(3);
+    chain_apply_lean<CH>(W, C.cs + wbase, np, lane, ch, n_steps, scan_levels);
     wave_lds_sync();
+    PGO_T(4);
     double* zt = vz + f0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -1996,12 +2112,15 @@ __global__ __launch_bounds__(WG) void k_cg_update1_cl(CgVec V, ChainPre C, int n
     }
     wave_lds_sync();
   }
-  rz = block_sum_bcast(rz, red);
-  rr = block_sum_bcast(rr, red);
+  PGO_T(5);
+  rz = block_sum_nw<NW>(rz, red);
+  rr = block_sum_nw<NW>(rr, red);
   if (tid == 0) {
     part_rz[blockIdx.x] = rz;
     part_rr[blockIdx.x] = rr;
   }
+  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) V.st->pending = 1;
+  PGO_T(6);
 }
 
 // ------------------------------------------------- METHOD 2: switch variables, eliminated edge by edge

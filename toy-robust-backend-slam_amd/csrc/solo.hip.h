@@ -193,17 +193,22 @@ __device__ __forceinline__ void solo_precond(const SoloArgs& S, const SoloProb& 
       if (INIT) {
         const double* bt = S.b + f0;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) rv[j] = (lane + 64u * j) < lim ? bt[lane + 64u * j] : 0.0;
+        for (int j = 0; j < NV; ++j) {
+          const unsigned e = lane + 64u * j;
+          const double v = bt[e < lim ? e : 0u];   // clamped address: no load behind a branch
+          rv[j] = e < lim ? v : 0.0;
+        }
       } else {
         double av[NV], yv[NV], pv[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-          const unsigned e = lane + 64u * j;
+          const unsigned e = lane + 64u * j, ec = e < lim ? e : 0u;   // clamped addresses: no load behind a branch
           const bool ok = e < lim;
-          rv[j] = ok ? vr[f0 + e] : 0.0;
-          av[j] = ok ? vap[f0 + e] : 0.0;
-          yv[j] = ok ? vy[f0 + e] : 0.0;
-          pv[j] = ok ? pown[f0 + e] : 0.0;
+          const double r_ = vr[f0 + ec], a_ = vap[f0 + ec], y_ = vy[f0 + ec], p_ = pown[f0 + ec];
+          rv[j] = ok ? r_ : 0.0;
+          av[j] = ok ? a_ : 0.0;
+          yv[j] = ok ? y_ : 0.0;
+          pv[j] = ok ? p_ : 0.0;
         }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {

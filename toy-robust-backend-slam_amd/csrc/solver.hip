@@ -104,6 +104,8 @@ struct pgo_handle {
   // chain (block-tridiagonal) preconditioner over 64-pose segments (opt.pcg_chain_len): C planes, W planes, S^-1 planes
   int chain_len = 0, g_chain = 1, chain_pad = 0;
   int chain_chunk = 0, chain_steps = 0;  // lean apply: poses per lane (2 / 4) and recurrence steps; 0 = scan kernel (layout chunk 4)
+  int chain_scan = 0;                    // > 0: the lean apply runs its recurrence as this many scan levels (few long segments)
+  int chain_nw = 4;                      // wavefronts per workgroup of the lean kernels: 1 on small graphs (a tile per CU)
   double *chain_c = nullptr, *chain_w = nullptr, *chain_s = nullptr;
   // halo exchange of the search direction (world > 1, opt.halo_exchange)
   bool use_halo = false;
@@ -140,6 +142,10 @@ struct pgo_handle {
   hipGraphExec_t cg_graph_exec = nullptr;
   int cg_graph_len = 0;
   int last_pcg_iters = 0;  // iteration count of the previous PCG solve of this handle (slice scheduling)
+  // small graphs on one rank: the direction update rides in the next SpMV (k_spmv MODE 5) -- two launches per PCG
+  // iteration instead of three; p_full / p_full2 alternate by iteration parity
+  bool fused_p = false;
+  double* p_full2 = nullptr;
   // batched handle (pgo_batch_*): the block-diagonal union of independent problems, each starting at a multiple of 256 rows
   bool batch_mode = false;
   std::vector<uint8_t> fixed_mask_h;    // set before create(): constant rows (one anchor per problem + the padding rows)
@@ -367,6 +373,11 @@ struct pgo_handle {
     A.y = yout;
     A.dot_part = dot_part;
     A.done = done;
+    A.z = nullptr;
+    A.p_new = nullptr;
+    A.part_rz = A.part_rr = nullptr;
+    A.n_rz = A.n_rr = A.parity = 0;
+    A.st = nullptr;
     return A;
   }
   int spmv_enqueue(const double* p, double* yout, double* dot_part, int with_d2, const int32_t* done) {
@@ -443,6 +454,8 @@ struct pgo_handle {
     V.ap = ap;
     V.p = p_full;
     V.st = st;
+    V.fused = 0;
+    V._pad = 0;
     return V;
   }
 
@@ -458,15 +471,18 @@ struct pgo_handle {
   void launch_cg_init_chain(const double* b, double* part_rz, double* part_bb) {
     const dev::CgVec V = cg_vec();
     const dev::ChainPre CP = chain_pre();
-    if (chain_chunk == 2) hipLaunchKernelGGL(dev::k_cg_init_cl<2>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, chain_steps, b, part_rz, part_bb);
-    else if (chain_chunk == 4) hipLaunchKernelGGL(dev::k_cg_init_cl<4>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, chain_steps, b, part_rz, part_bb);
+    if (chain_chunk == 2 && chain_nw == 4) hipLaunchKernelGGL((dev::k_cg_init_cl<2, 4>), dim3(g_chain), dim3(256), 0, stream, V, CP, chain_steps, chain_scan, b, part_rz, part_bb);
+    else if (chain_chunk == 2) hipLaunchKernelGGL((dev::k_cg_init_cl<2, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, chain_steps, chain_scan, b, part_rz, part_bb);
+    else if (chain_chunk == 4 && chain_nw == 4) hipLaunchKernelGGL((dev::k_cg_init_cl<4, 4>), dim3(g_chain), dim3(256), 0, stream, V, CP, chain_steps, chain_scan, b, part_rz, part_bb);
+    else if (chain_chunk == 4) hipLaunchKernelGGL((dev::k_cg_init_cl<4, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, chain_steps, chain_scan, b, part_rz, part_bb);
     else hipLaunchKernelGGL(dev::k_cg_init_c, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, b, part_rz, part_bb);
   }
-  void launch_cg_update1_chain(int par, const double* pap, int n_pap, double* part_rz, double* part_rr) {
-    const dev::CgVec V = cg_vec();
+  void launch_cg_update1_chain(const dev::CgVec& V, int par, const double* pap, int n_pap, double* part_rz, double* part_rr) {
     const dev::ChainPre CP = chain_pre();
-    if (chain_chunk == 2) hipLaunchKernelGGL(dev::k_cg_update1_cl<2>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, chain_steps, par, pap, n_pap, part_rz, part_rr);
-    else if (chain_chunk == 4) hipLaunchKernelGGL(dev::k_cg_update1_cl<4>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, chain_steps, par, pap, n_pap, part_rz, part_rr);
+    if (chain_chunk == 2 && chain_nw == 4) hipLaunchKernelGGL((dev::k_cg_update1_cl<2, 4>), dim3(g_chain), dim3(256), 0, stream, V, CP, chain_steps, chain_scan, par, pap, n_pap, part_rz, part_rr);
+    else if (chain_chunk == 2) hipLaunchKernelGGL((dev::k_cg_update1_cl<2, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, chain_steps, chain_scan, par, pap, n_pap, part_rz, part_rr);
+    else if (chain_chunk == 4 && chain_nw == 4) hipLaunchKernelGGL((dev::k_cg_update1_cl<4, 4>), dim3(g_chain), dim3(256), 0, stream, V, CP, chain_steps, chain_scan, par, pap, n_pap, part_rz, part_rr);
+    else if (chain_chunk == 4) hipLaunchKernelGGL((dev::k_cg_update1_cl<4, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, chain_steps, chain_scan, par, pap, n_pap, part_rz, part_rr);
     else hipLaunchKernelGGL(dev::k_cg_update1_c, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, par, pap, n_pap, part_rz, part_rr);
   }
 
@@ -713,7 +729,19 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     if (chain_chunk) {
       chain_steps = chain_len / chain_chunk - 1;
       const int64_t n_wt = (NL + 64 * chain_chunk - 1) / (64 * chain_chunk);
-      g_chain = (int)std::min<int64_t>((n_wt + 3) / 4, 2048);
+      // Small graphs (few tiles, nothing to overlap with): one wavefront per workgroup, so that every tile loads through
+      // its own CU's L1, and -- for segments of more than 16 lanes -- the recurrence as a log-depth scan (INTEL, 256-pose
+      // segments: 7.4 -> 4.8 us per apply); large graphs keep the 4-wave workgroups and the serial DPP recurrence,
+      // which needs fewer registers and no LDS-crossbar shuffles.
+      const bool small = n_wt <= 512;
+      chain_nw = small ? 1 : 4;
+      chain_scan = 0;
+      if (small && chain_len / chain_chunk > 16)
+        for (int l = 1; l < chain_len / chain_chunk; l <<= 1) ++chain_scan;
+      if (const char* cs = getenv("PGO_CHAIN_SCAN")) {  // experiments: 0 = always serial
+        if (atoi(cs) == 0) chain_scan = 0;
+      }
+      g_chain = (int)std::min<int64_t>((n_wt + chain_nw - 1) / chain_nw, 2048);
     }
   } else {
     chain_len = 0;
@@ -732,7 +760,9 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       chain_chunk = dev::SOLO_CH;  // the 256-row tile layout of the factor planes
       chain_steps = chain_len / chain_chunk - 1;
       const int64_t n_wt = (NL + 64 * chain_chunk - 1) / (64 * chain_chunk);
-      g_chain = (int)std::min<int64_t>((n_wt + 3) / 4, 2048);
+      chain_nw = n_wt <= 512 ? 1 : 4;
+      chain_scan = 0;
+      g_chain = (int)std::min<int64_t>((n_wt + chain_nw - 1) / chain_nw, 2048);
       const int lanes = chain_len / dev::SOLO_CH;  // lanes per segment: serial recurrence up to 16, else log-depth scan
       solo_steps = lanes - 1;
       solo_scan = 0;
@@ -746,6 +776,11 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       HIPC(hipHostMalloc((void**)&h_solo, sizeof(dev::SoloOut)));
     }
     solo = ok;
+  }
+  {
+    const char* fe = getenv("PGO_FUSED_P");
+    fused_p = !(fe && fe[0] == '0') && world == 1 && !force_collectives && !batch_mode && NL > 0 && NL <= 16384;
+    if (fused_p) PGOC(dalloc(&p_full2, dev::PS * n_full));
   }
   if (!fixed_mask_h.empty()) {
     PGOC(dalloc(&fixed_mask, (int64_t)fixed_mask_h.size()));
@@ -924,17 +959,36 @@ int pgo_handle::pcg(int* iters, double* rel) {
   const int max_it = std::max(0, opt.pcg_max_iters);
   int every = std::max(1, opt.pcg_check_every);
   // one PCG iteration = 3 dependent launches; `par` is the r.z double-buffer parity baked into the arguments
+  const bool fused = fused_p && !multi;
+  double* pbuf[2] = {p_full, p_full2};
+  if (fused) HIPC(hipMemsetAsync(p_full2, 0, (size_t)dev::PS * n_full * sizeof(double), stream));  // "p_old" of iteration 0
   auto enqueue_iteration = [&](int par) -> int {
     int n_sp = g_spmv;
-    if (overlap) PGOC(spmv_with_halo(p_full, ap, part[0], &st->done, &n_sp));  // p reaches the peers inside
+    dev::CgVec Vi = V;
+    if (fused) {
+      // the previous iteration's direction update happens inside this SpMV: p_old = pbuf[par ^ 1] -> p_new = pbuf[par]
+      dev::SpmvArgs A = spmv_args(pbuf[par ^ 1], ap, part[0], 1, &st->done);
+      A.z = z;
+      A.p_new = pbuf[par];
+      A.part_rz = part[1];
+      A.part_rr = part[2];
+      A.n_rz = A.n_rr = g_u1;
+      A.parity = par ^ 1;
+      A.st = st;
+      hipLaunchKernelGGL(dev::k_spmv_t<5>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+      PGOC(check_launch("k_spmv (fused direction update)"));
+      Vi.p = pbuf[par];
+      Vi.fused = 1;
+    } else if (overlap) PGOC(spmv_with_halo(p_full, ap, part[0], &st->done, &n_sp));  // p reaches the peers inside
     else PGOC(spmv_enqueue(p_full, ap, part[0], 1, &st->done));
     const double* pap = multi ? scal + 6 : part[0];
     const int n_pap = multi ? 1 : n_sp;
     if (multi) PGOC(reduce_to_scal({{part[0], n_sp, 0}}, 6));
-    if (chained) launch_cg_update1_chain(par, pap, n_pap, part[1], part[2]);
-    else if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, par, pap, n_pap, part[1], part[2]);
-    else hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_u1), dim3(dev::WG), 0, stream, V, par, pap, n_pap, part[1], part[2]);
+    if (chained) launch_cg_update1_chain(Vi, par, pap, n_pap, part[1], part[2]);
+    else if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, GP, par, pap, n_pap, part[1], part[2]);
+    else hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, par, pap, n_pap, part[1], part[2]);
     PGOC(check_launch("k_cg_update1"));
+    if (fused) return PGO_OK;  // its r.z / r.r partials are booked by the next SpMV, or by k_cg_book at the end of the slice
     if (multi) {
       PGOC(reduce_to_scal({{part[1], g_u1, 0}, {part[2], g_u1, 0}}, 7));
       hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
@@ -959,6 +1013,10 @@ int pgo_handle::pcg(int* iters, double* rel) {
       HIPC(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       int st_cap = PGO_OK;
       for (int c = 0; c < every && st_cap == PGO_OK; ++c) st_cap = enqueue_iteration(c & 1);
+      if (fused && st_cap == PGO_OK) {
+        hipLaunchKernelGGL(dev::k_cg_book, dim3(1), dim3(dev::WG), 0, stream, st, (every - 1) & 1, (const double*)part[1], g_u1, (const double*)part[2], g_u1);
+        st_cap = check_launch("k_cg_book");
+      }
       hipError_t e_end = hipStreamEndCapture(stream, &gr);
       PGOC(st_cap);
       if (e_end != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end));
@@ -982,6 +1040,10 @@ int pgo_handle::pcg(int* iters, double* rel) {
         HIPC(hipGraphLaunch(cg_graph_exec, stream));
       } else {
         for (int c = 0; c < chunk; ++c) PGOC(enqueue_iteration((it + c) & 1));
+        if (fused && chunk > 0) {
+          hipLaunchKernelGGL(dev::k_cg_book, dim3(1), dim3(dev::WG), 0, stream, st, (it + chunk - 1) & 1, (const double*)part[1], g_u1, (const double*)part[2], g_u1);
+          PGOC(check_launch("k_cg_book"));
+        }
       }
       it += chunk;
     }
@@ -1522,6 +1584,15 @@ int pgo_solve_batch(pgo_t* const* handles, int32_t n, pgo_summary* summaries, in
   if (first_status != PGO_OK) return fail(first_status, first_msg);
   return PGO_OK;
 }
+
+#ifdef PGO_PHASE_TIMING
+// experiment builds only (scripts/exp_phase.sh): wall_clock64 stamps of the last k_cg_update1_cl launch
+int pgo_debug_phase_times(pgo_t* h, unsigned long long* out16) {
+  HIPC(hipStreamSynchronize(h->stream));
+  HIPC(hipMemcpyFromSymbol(out16, HIP_SYMBOL(dev::g_phase_t), 16 * sizeof(unsigned long long)));
+  return PGO_OK;
+}
+#endif
 
 int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   if (!h || !out) return fail(PGO_ERR_INVALID_ARG, "pgo_get_info: null");

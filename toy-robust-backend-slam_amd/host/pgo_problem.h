@@ -197,10 +197,76 @@ struct SolverAccess {
     const int st = pgo_solve(h, &sum->s);
     Finish(pr, h, st, sum);
   }
-  // The layer managers' pattern (src/simple_layer_manager.cpp:457-622: one ceres::Solve per candidate layer / window):
-  // independent problems solved concurrently through pgo_solve_batch.
+  // The layer managers' pattern (src/simple_layer_manager.cpp:457-622: one ceres::Solve per candidate layer / window).
+  // ONE batched handle (pgo_batch_*: a workgroup per problem, per-problem LM state on one launch sequence) when every
+  // problem uses the same plain / DCS functor, loss and anchor index; else a pool of host threads over ordinary handles.
+  static bool BatchEligible(const std::vector<Problem*>& prs) {
+    if (prs.empty()) return false;
+    for (Problem* pr : prs)
+      if (pr->mixed_loss_ || pr->any_sc_ || pr->any_dcs_ != prs[0]->any_dcs_ || pr->delta_ != prs[0]->delta_ ||
+          pr->fixed_ != prs[0]->fixed_ || pr->ptr_.empty())
+        return false;
+    return true;
+  }
   static void SolveBatch(const Solver::Options& opt, const std::vector<Problem*>& prs, std::vector<Solver::Summary>* sums,
                          int max_concurrency) {
+    if (BatchEligible(prs)) {
+      std::vector<pgo_graph*> gs(prs.size(), nullptr);
+      pgo_batch_t* b = nullptr;
+      auto cleanup = [&] {
+        for (pgo_graph* g : gs) pgo_graph_free(g);
+        if (b) pgo_batch_destroy(b);
+      };
+      try {
+        for (size_t i = 0; i < prs.size(); ++i) {
+          Problem* pr = prs[i];
+          const int32_t N = (int32_t)pr->ptr_.size(), E = (int32_t)pr->ia_.size();
+          std::vector<double> poses((size_t)3 * N);
+          for (int32_t k = 0; k < N; ++k)
+            for (int c = 0; c < 3; ++c) poses[3 * (size_t)k + c] = pr->ptr_[k][c];
+          check(pgo_graph_from_arrays(N, poses.data(), E, pr->ia_.data(), pr->ib_.data(), pr->meas_.data(), nullptr, pr->kind_.data(), &gs[i]));
+        }
+        pgo_options o;
+        pgo_options_default(&o);
+        o.method = prs[0]->any_dcs_ ? 1 : 0;
+        o.huber_delta = prs[0]->delta_;
+        o.fixed_pose = prs[0]->fixed_;
+        o.max_iters = opt.max_num_iterations;
+        o.ftol = opt.function_tolerance;
+        o.gtol = opt.gradient_tolerance;
+        o.ptol = opt.parameter_tolerance;
+        o.radius0 = opt.initial_trust_region_radius;
+        o.pcg_rtol = opt.pcg_rtol;
+        o.pcg_max_iters = opt.pcg_max_iters;
+        int st = pgo_batch_create(&b, (int32_t)prs.size(), gs.data(), &o, opt.device);
+        if (st != PGO_ERR_UNSUPPORTED) {
+          check(st);
+          std::vector<pgo_summary> raw(prs.size());
+          check(pgo_batch_solve(b, raw.data()));
+          sums->assign(prs.size(), Solver::Summary());
+          for (size_t i = 0; i < prs.size(); ++i) {
+            Problem* pr = prs[i];
+            const int32_t N = (int32_t)pr->ptr_.size();
+            std::vector<double> poses((size_t)3 * N);
+            check(pgo_batch_get_poses(b, (int32_t)i, poses.data()));
+            for (int32_t k = 0; k < N; ++k)
+              for (int c = 0; c < 3; ++c) pr->ptr_[k][c] = poses[3 * (size_t)k + c];
+            Solver::Summary& sm = (*sums)[i];
+            sm.s = raw[i];
+            sm.iterations.resize((size_t)pgo_batch_num_iter_records(b, (int32_t)i));
+            check(pgo_batch_get_iter_records(b, (int32_t)i, sm.iterations.data(), (int32_t)sm.iterations.size()));
+            sm.num_parameter_blocks = N;
+            sm.num_residual_blocks = (int)pr->ia_.size();
+          }
+          cleanup();
+          return;
+        }
+      } catch (...) {
+        cleanup();
+        throw;
+      }
+      cleanup();  // a problem the batched handle does not take (a row with > 256 edges): the thread pool below
+    }
     std::vector<pgo_t*> hs;
     try {
       for (Problem* pr : prs) hs.push_back(Prepare(opt, pr));
