@@ -32,6 +32,7 @@ struct RcclComm final : pgo_comm {
   ~RcclComm() override {
     if (comm) ncclCommDestroy(comm);
   }
+  bool capturable() const override { return true; }
   int allreduce(double* dev, int n, bool is_max, hipStream_t s) override {
     ncclResult_t r = ncclAllReduce(dev, dev, (size_t)n, ncclDouble, is_max ? ncclMax : ncclSum, comm, s);
     if (r != ncclSuccess) return fail(PGO_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));

@@ -6,6 +6,9 @@
 struct pgo_comm {
   int rank = 0, world = 1, device = 0;
   virtual ~pgo_comm() {}
+  // true when the collectives are pure stream work and may be recorded into a hipGraph (RCCL); the host-staged test
+  // back-end blocks on the host inside every call and may not
+  virtual bool capturable() const { return false; }
   // in-place all-reduce of n doubles in device memory (sum or max), ordered on `s`
   virtual int allreduce(double* dev, int n, bool is_max, hipStream_t s) = 0;
   // in-place all-gather: rank r's `count_per_rank` doubles live at base + r*count_per_rank

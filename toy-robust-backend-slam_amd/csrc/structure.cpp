@@ -28,11 +28,27 @@ int compute_pose_order(int32_t N, int32_t E, const int32_t* ia, const int32_t* i
     std::iota(perm->begin(), perm->end(), 0);
     return PGO_OK;
   }
-  // supported loop edges -> edges of the segment graph
-  std::unordered_set<int64_t> pairs;
-  pairs.reserve((size_t)E * 2);
-  auto key = [N](int64_t a, int64_t b) { return a < b ? a * N + b : b * N + a; };
-  for (int32_t e = 0; e < E; ++e) pairs.insert(key(ia[e], ib[e]));
+  // supported loop edges -> edges of the segment graph.  "Is there an edge {x, y}?" is answered from a symmetric
+  // adjacency in CSR form with sorted rows (two counting passes + a per-row sort; a hash set of the 4M pairs of the
+  // 1M-pose graph took 2.1 s here, on every rank)
+  std::vector<int64_t> aptr((size_t)N + 1, 0);
+  for (int32_t e = 0; e < E; ++e) {
+    aptr[(size_t)ia[e] + 1]++;
+    aptr[(size_t)ib[e] + 1]++;
+  }
+  for (int32_t i = 0; i < N; ++i) aptr[(size_t)i + 1] += aptr[i];
+  std::vector<int32_t> adj_col((size_t)aptr[N]);
+  {
+    std::vector<int64_t> fill(aptr.begin(), aptr.end() - 1);
+    for (int32_t e = 0; e < E; ++e) {
+      adj_col[(size_t)fill[ia[e]]++] = ib[e];
+      adj_col[(size_t)fill[ib[e]]++] = ia[e];
+    }
+    for (int32_t i = 0; i < N; ++i) std::sort(adj_col.begin() + aptr[i], adj_col.begin() + aptr[(size_t)i + 1]);
+  }
+  auto has_edge = [&](int64_t x, int64_t y) {
+    return std::binary_search(adj_col.begin() + aptr[x], adj_col.begin() + aptr[x + 1], (int32_t)y);
+  };
   std::vector<std::pair<int32_t, int32_t>> seg_edges;
   for (int32_t e = 0; e < E; ++e) {
     const int64_t a = ia[e], b = ib[e];
@@ -44,7 +60,7 @@ int compute_pose_order(int32_t N, int32_t E, const int32_t* ia, const int32_t* i
         if (da == 0 && db == 0) continue;
         const int64_t x = a + da, y = b + db;
         if (x < 0 || y < 0 || x >= N || y >= N || x == y) continue;
-        ok = pairs.count(key(x, y)) != 0;
+        ok = has_edge(x, y);
       }
     if (ok) seg_edges.emplace_back(std::min(sa, sb), std::max(sa, sb));
   }
