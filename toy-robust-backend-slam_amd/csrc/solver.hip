@@ -141,6 +141,7 @@ struct pgo_handle {
   // captured slice of PCG iterations (world == 1)
   hipGraphExec_t cg_graph_exec = nullptr;
   int cg_graph_len = 0;
+  bool graph_failed = false, graph_collectives = true;
   int last_pcg_iters = 0;  // iteration count of the previous PCG solve of this handle (slice scheduling)
   // small graphs on one rank: the direction update rides in the next SpMV (k_spmv MODE 5) -- two launches per PCG
   // iteration instead of three; p_full / p_full2 alternate by iteration parity
@@ -525,6 +526,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   const char* fc = getenv("PGO_FORCE_COLLECTIVES");
   force_collectives = fc && fc[0] == '1';
   if (const char* nt = getenv("PGO_SPMV_NT")) spmv_nt = atoi(nt);
+  if (const char* gc = getenv("PGO_GRAPH_COLLECTIVES")) graph_collectives = gc[0] != '0';
   grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
   chain_len = pgo::resolve_chain_len(opt.pcg_chain_len, opt.pcg_block_poses, N, E, ia, ib);
   if (chain_len != 0 && (chain_len < dev::CHAIN_CHUNK || chain_len % dev::CHAIN_CHUNK != 0 || dev::CHAIN_TILE % chain_len != 0))
@@ -1003,7 +1005,12 @@ int pgo_handle::pcg(int* iters, double* rel) {
   // Launch-bound regime (small graphs): a slice of `every` iterations is captured ONCE per handle into a
   // hipGraph (every argument is fixed for the handle's lifetime; the slice length is even so the parity
   // pattern repeats) and replayed with a single host call per slice.
-  const bool use_graph = opt.use_graphs && !multi;
+  // Several ranks: the slice is captured WITH its RCCL calls (all-reduces of the dot products, halo exchange or
+  // all-gather of the search direction) when they are pure stream work and everything runs on the one solver stream
+  // -- otherwise every PCG iteration costs the host ~7 kernel launches + 3 collective calls, about the device time of
+  // an iteration at 8 shards of the 1M-pose graph.  PGO_GRAPH_COLLECTIVES=0 keeps the eager loop; a capture that fails
+  // falls back to it for the rest of the handle's life.
+  bool use_graph = opt.use_graphs && !graph_failed && (!multi || (comm->capturable() && !overlap && graph_collectives));
   if (use_graph) {
     every += every & 1;
     if (!cg_graph_exec || cg_graph_len != every) {
@@ -1018,12 +1025,26 @@ int pgo_handle::pcg(int* iters, double* rel) {
         st_cap = check_launch("k_cg_book");
       }
       hipError_t e_end = hipStreamEndCapture(stream, &gr);
-      PGOC(st_cap);
-      if (e_end != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end));
-      hipError_t e_inst = hipGraphInstantiate(&cg_graph_exec, gr, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(gr);
-      if (e_inst != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e_inst));
-      cg_graph_len = every;
+      hipError_t e_inst = hipSuccess;
+      if (st_cap == PGO_OK && e_end == hipSuccess) {
+        e_inst = hipGraphInstantiate(&cg_graph_exec, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+      }
+      if (st_cap != PGO_OK || e_end != hipSuccess || e_inst != hipSuccess) {
+        if (!multi) {  // single rank: a capture failure is a real error
+          PGOC(st_cap);
+          if (e_end != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end));
+          return fail(PGO_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e_inst));
+        }
+        // with collectives inside: run eagerly from now on (every rank takes the same decision: same library, same calls)
+        (void)hipGetLastError();
+        cg_graph_exec = nullptr;
+        graph_failed = true;
+        use_graph = false;
+        if (opt.verbose) printf("pgo: hipGraph capture of the PCG slice with collectives failed; eager launches from here on\n");
+      } else {
+        cg_graph_len = every;
+      }
     }
   }
   // Slices enqueued after convergence are not free: each of their launches early-outs on st->done but still costs
