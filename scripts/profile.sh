@@ -5,13 +5,13 @@
 #   pass 3: --pmc WRITE_SIZE
 # Raw output goes to gpurun_out/prof_<tag>/ ; scripts/summarize_profile.py condenses it into profiles/.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 3 --warmup 1 --cpu-iters 0 --kernel-reps 5"
+ARGS="bench.py --steps 3 --warmup 1 --passes 1 --workloads 0 --cpu-iters 0 --kernel-reps 5"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
-PMCARGS="bench.py --steps 1 --warmup 0 --cpu-iters 0 --kernel-reps 3 --pcg-max-iters 10"
+PMCARGS="bench.py --steps 1 --warmup 0 --passes 1 --workloads 0 --cpu-iters 0 --kernel-reps 3 --pcg-max-iters 10"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $PMCARGS > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $PMCARGS > $OUT/pmc_write.log 2>&1 || { tail -5 $OUT/pmc_write.log; exit 1; }
 find $OUT -name "*.csv" | xargs ls -la

@@ -28,7 +28,7 @@ def read_csv(pattern):
 def short(name):
     n = name
     for k in ("k_edge_eval<true", "k_edge_eval<false", "k_edge_evalILb1", "k_edge_evalILb0", "k_edge_chi2", "k_assemble", "k_spmv",
-              "k_cg_update1_c", "k_cg_update1_g", "k_cg_update1", "k_cg_update2", "k_cg_init_fin", "k_cg_init_c", "k_cg_init_g", "k_cg_init",
+              "k_cg_update1_cl", "k_cg_update1_c", "k_cg_update1_g", "k_cg_update1", "k_cg_update2", "k_cg_init_fin", "k_cg_init_cl", "k_cg_init_c", "k_cg_init_g", "k_cg_init",
               "k_chain_factor", "k_chain_extract", "k_prepare_groups", "k_prepare", "k_finalize", "k_dot",
               "k_candidate", "k_scatter_owned", "k_grad_max", "k_xnorm", "k_jacobi_scale", "k_flag_to_double", "k_fill"):
         if k in n:
@@ -61,7 +61,7 @@ def main():
         f = [v for v in d if v > 0.5 * p90]
         return sum(f) / len(f), len(f)
 
-    lines = ["# rocprofv3 --kernel-trace --stats, bench.py --steps 3 --warmup 1 (1M poses, 1 GPU)", "",
+    lines = ["# rocprofv3 --kernel-trace --stats, bench.py --steps 3 --warmup 1 --passes 1 --workloads 0 (1M poses, 1 GPU)", "",
              "| kernel | calls | total ms | avg us | % | full launches | full avg us |", "|---|---|---|---|---|---|---|"]
     with open(os.path.join(prof, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
         if stats:
@@ -110,7 +110,11 @@ def main():
         cal["write_factor_k_scatter"] = n_bytes / (pmc["k_scatter_owned"]["write_kib"] * 1024)
     rf = cal.get("read_factor_k_dot", 2.0)
     wf = cal.get("write_factor_k_scatter", 1.0)
-    traffic = {"calibration": cal, "read_factor_used": rf, "write_factor_used": wf,
+    import hashlib
+    hh = hashlib.sha256()
+    for f in ("kernels.hip.h", "solver.hip"):
+        hh.update(open(os.path.join(root, "toy-robust-backend-slam_amd", "csrc", f), "rb").read())
+    traffic = {"kernels_digest": hh.hexdigest()[:16], "profile_tag": tag, "calibration": cal, "read_factor_used": rf, "write_factor_used": wf,
                "note": "bytes per launch = FETCH_SIZE*1024*read_factor + WRITE_SIZE*1024*write_factor (gfx950: FETCH_SIZE "
                        "counts half the bytes of coalesced streaming reads, MI355X_MICROARCH.md section HBM; factors "
                        "calibrated on k_dot / k_scatter_owned, whose byte counts are known)"}

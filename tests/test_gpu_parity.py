@@ -233,6 +233,36 @@ def test_lm_solve_matches_golden(pgo, name, n_out, method):
     s.close()
 
 
+def test_duplicate_edges_are_summed_in_a_fixed_order(pgo, oracle):
+    """several edges between the same two poses (CSAIL has one such pair; here every fifth odometry pair is tripled and
+    every loop doubled) inside the dense pose-block preconditioner: the blocks of a pair are summed by ONE thread in the
+    caller's edge order (k_prepare_groups), so repeated solves are bitwise identical -- and equal to the C port"""
+    g0 = load(pgo, "MIT")
+    poses, ia, ib, meas, kind = (np.array(x) for x in (g0.poses, g0.ia, g0.ib, g0.meas, g0.kind))
+    rng = np.random.default_rng(11)
+    odo = np.nonzero(kind == 0)[0][::5]
+    loops = np.nonzero(kind != 0)[0]
+    extra = np.concatenate([odo, odo, loops])
+    ia2, ib2 = np.concatenate([ia, ia[extra]]), np.concatenate([ib, ib[extra]])
+    meas2 = np.concatenate([meas, meas[extra] + 0.01 * rng.standard_normal((len(extra), 3))])
+    kind2 = np.concatenate([kind, kind[extra]])
+    order = np.argsort(kind2, kind="stable")                 # keep the odometry | closure grouping
+    g = pgo.Graph.from_arrays(poses, ia2[order], ib2[order], meas2[order], kind2[order])
+    kw = dict(method=1, max_iters=6, pcg_block_poses=32, pcg_chain_len=0, pcg_rtol=1e-10, pcg_max_iters=100000)
+    runs = []
+    for _ in range(4):
+        s = pgo.Solver(g, pgo.Options(**kw))
+        sm = s.solve()
+        runs.append((s.poses(), sm.total_pcg_iters, sm.final_cost))
+        s.close()
+    for x, it, c in runs[1:]:
+        np.testing.assert_array_equal(x, runs[0][0])
+        assert it == runs[0][1] and c == runs[0][2]
+    ores = oracle.lm_pcg(oracle_graph(oracle, g), oracle.Options(threads=4, **kw))
+    assert runs[0][2] == pytest.approx(ores.final_cost, rel=1e-9)
+    assert np.abs(runs[0][0] - ores.poses).max() < 1e-6
+
+
 def test_dcs_survives_outliers_plain_collapses(pgo):
     """The one behavioural result the reference publishes (README.md:38-44, docs/report.png): on INTEL with 50 injected
     outlier loops the trajectory survives with DCS ON and collapses with DCS OFF.  Asserted on the HIP path (50 LM

@@ -444,6 +444,10 @@ __global__ __launch_bounds__(WG) void k_edge_chi2(EdgeArgs A, const int32_t* __r
   }
 }
 
+// input record of the chain factorisation, one 128-byte line per row: M_ii = H_ii + D'D (6: 00 01 02 11 12 22) | C_i = the
+// sum of the blocks (i, i-1) of row i, row-major (9; 0 at a segment start) | pad
+constexpr int CHAIN_REC = 16;
+
 // ------------------------------------------------------------------- K2
 // local row (in [r0, r1)) whose incidence range contains q: binary search in inc_ptr (<= 8 steps, L1/L2 hits)
 __device__ __forceinline__ int upper_row(const int32_t* __restrict__ inc_ptr, int r0, int r1, int q) {
@@ -477,6 +481,9 @@ struct AsmArgs {
   const double* sw_gamma;
   double* diag_full;         // [n_loc x 3]
   double* gs_full;           // [n_loc x 3]
+  // chain preconditioner: input records of the factorisation (CHAIN_REC doubles per row, C part written here); nullptr = off
+  double* chain_rec;
+  int32_t chain_seg;
 };
 
 // One workgroup per tile of rows.  Phase A: one lane per incidence reads the
@@ -515,8 +522,8 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
         }
         // Jacobi column scales of this row's pose and of the other endpoint
         double ss[3], so[3];
+        const int row = (int)(upper_row(A.inc_ptr, r0, r1, q));
         {
-          const int row = (int)(upper_row(A.inc_ptr, r0, r1, q));
           const double* s_self = A.scale + 3 * (int64_t)(A.lo + row);
           const double* s_oth = A.scale + 3 * col;
           ss[0] = s_self[0]; ss[1] = s_self[1]; ss[2] = s_self[2];
@@ -560,6 +567,18 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
             HB[3 * a + b] = v;
           }
         hoff_store(A.hoff, q, HB);
+        // chain preconditioner: the block (i, i-1) goes straight into the factorisation's input record (C part), so that
+        // no kernel has to dig it out of the AoSoA block stream again (k_chain_extract read 975 MB to find 72 MB).  With
+        // several edges between i-1 and i the first incidence writes and k_chain_dupfix replaces it by the ordered sum.
+        if (A.chain_rec != nullptr && col == (int64_t)A.lo + row - 1 && (row % A.chain_seg) != 0 &&
+            (q == A.inc_ptr[row] || A.inc_col[q - 1] != (int32_t)col)) {
+          double2* o = reinterpret_cast<double2*>(A.chain_rec + (int64_t)row * CHAIN_REC + 6);
+          o[0] = make_double2(HB[0], HB[1]);
+          o[1] = make_double2(HB[2], HB[3]);
+          o[2] = make_double2(HB[4], HB[5]);
+          o[3] = make_double2(HB[6], HB[7]);
+          A.chain_rec[(int64_t)row * CHAIN_REC + 14] = HB[8];
+        }
         double d0 = S[0] * S[0] + S[3] * S[3] + S[6] * S[6], d1 = S[0] * S[1] + S[3] * S[4] + S[6] * S[7];
         double d2 = S[0] * S[2] + S[3] * S[5] + S[6] * S[8], d3 = S[1] * S[1] + S[4] * S[4] + S[7] * S[7];
         double d4 = S[1] * S[2] + S[4] * S[5] + S[7] * S[8], d5 = S[2] * S[2] + S[5] * S[5] + S[8] * S[8];
@@ -915,7 +934,7 @@ __global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo,
 __global__ void k_prepare(const double* __restrict__ hd, const double* __restrict__ diag_full, int n_loc, int lo, int fixed,
                           double radius, double dmin, double dmax, double* __restrict__ d2, double* __restrict__ minv,
                           const uint8_t* __restrict__ fixed_mask, const int32_t* __restrict__ prob_of_256,
-                          const double* __restrict__ prob_radius) {
+                          const double* __restrict__ prob_radius, double* __restrict__ chain_rec) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_loc) return;
   if (fixed_mask && fixed_mask[row]) fixed = lo + row;
@@ -935,6 +954,13 @@ __global__ void k_prepare(const double* __restrict__ hd, const double* __restric
   a00 += e0;
   a11 += e1;
   a22 += e2;
+  if (chain_rec) {  // chain preconditioner: M_ii = H_ii + D'D into the factorisation's input record (the 3x3 inverse below is unused)
+    double2* o = reinterpret_cast<double2*>(chain_rec + (int64_t)row * CHAIN_REC);
+    o[0] = make_double2(a00, a01);
+    o[1] = make_double2(a02, a11);
+    o[2] = make_double2(a12, a22);
+    return;
+  }
   const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
   const double det = a00 * c00 + a01 * c01 + a02 * c02;
   const double id = 1.0 / det;
@@ -1192,11 +1218,20 @@ __global__ __launch_bounds__(WG) void k_prepare_groups(GroupPrepArgs A) {
         const int col = A.inc_col[q] - A.lo;
         if (col >= g0 && col < g1) {
           const int row = upper_row(A.inc_ptr, g0, g1, q);
-          double h[9];
-          hoff_load(A.hoff, q, h);
+          // Several edges may join the same two poses: their blocks are adjacent in the row (incidences are sorted by
+          // column, then by the caller's edge index).  The FIRST incidence of such a run sums the run in that order and
+          // is the only writer of the (row, col) block -- no atomics, so the sum does not depend on the thread schedule.
+          if (q > A.inc_ptr[row] && A.inc_col[q - 1] - A.lo == col) continue;
+          double acc[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          const int q_end = A.inc_ptr[row + 1];
+          for (int qq = q; qq < q_end && A.inc_col[qq] - A.lo == col; ++qq) {
+            double h[9];
+            hoff_load(A.hoff, qq, h);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) acc[c] += h[c];
+          }
           for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b)
-              atomicAdd(&M[(3 * (row - g0) + a) * ld + 3 * (col - g0) + b], h[3 * a + b]);  // duplicate pairs add up
+            for (int b = 0; b < 3; ++b) M[(3 * (row - g0) + a) * ld + 3 * (col - g0) + b] += acc[3 * a + b];  // (+= the zero / nothing else writes here)
         }
       }
     }
@@ -1351,42 +1386,39 @@ struct ChainPre {
   int32_t n_pad;      // n_loc rounded up to whole 256-row tiles
 };
 
-// Input record of the factorisation, one 128-byte line per row: M_ii = H_ii + D'D (6: 00 01 02 11 12 22) | C_i = the sum
-// of the off-diagonal blocks (i, i-1) of row i, row-major (9; 0 at a segment start) | pad.  One thread per row.
-constexpr int CHAIN_REC = 16;
-__global__ void k_chain_extract(const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_col,
-                                const double* __restrict__ hoff, const double* __restrict__ hd, const double* __restrict__ d2,
-                                int n_loc, int lo, int seg_len, double* __restrict__ rec) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= n_loc) return;
-  const int64_t n = n_loc;
+// Rows whose block (i, i-1) is the sum of several edges' blocks (listed at create; rare): the C part of their record is
+// rewritten as the sum over the run of incidences in incidence order.  One thread per listed row.
+__global__ void k_chain_dupfix(const int32_t* __restrict__ rows, int n_rows, const int32_t* __restrict__ inc_ptr,
+                               const int32_t* __restrict__ inc_col, const double* __restrict__ hoff, int lo,
+                               double* __restrict__ rec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_rows) return;
+  const int row = rows[k], target = lo + row - 1;
   double acc[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if ((row % seg_len) != 0) {
-    const int target = lo + row - 1;
-    for (int q = inc_ptr[row]; q < inc_ptr[row + 1]; ++q)
-      if (inc_col[q] == target) {
+  for (int q = inc_ptr[row]; q < inc_ptr[row + 1]; ++q)
+    if (inc_col[q] == target) {
+      double h[9];
+      hoff_load(hoff, q, h);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) acc[c] += hoff[hoff_index(c, q)];
-      }
-  }
-  double2* out = reinterpret_cast<double2*>(rec + (int64_t)row * CHAIN_REC);
-  out[0] = make_double2(hd[row] + d2[3 * (int64_t)row], hd[n + row]);
-  out[1] = make_double2(hd[2 * n + row], hd[3 * n + row] + d2[3 * (int64_t)row + 1]);
-  out[2] = make_double2(hd[4 * n + row], hd[5 * n + row] + d2[3 * (int64_t)row + 2]);
-  out[3] = make_double2(acc[0], acc[1]);
-  out[4] = make_double2(acc[2], acc[3]);
-  out[5] = make_double2(acc[4], acc[5]);
-  out[6] = make_double2(acc[6], acc[7]);
-  out[7] = make_double2(acc[8], 0.0);
+      for (int c = 0; c < 9; ++c) acc[c] += h[c];
+    }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) rec[(int64_t)row * CHAIN_REC + 6 + c] = acc[c];
 }
 
-// one thread per segment, sequential along the chain (seg_len dependent 3x3 steps; once per LM iteration); each step
-// reads one 128-byte record.  The records do not depend on the recurrence, so the loads of the next PF steps are kept in
-// flight while a step computes (a ring of PF records in registers): the chain is then paced by the 3x3 arithmetic, not
-// by one memory round trip per step (217 -> us at 1M poses / 64-pose segments; 206 us on INTEL's 256-pose segments).
-__global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len, int chunk,
-                               double* __restrict__ cw, double* __restrict__ cs) {
-  constexpr int PF = 4;
+// One thread per segment, sequential along the chain (seg_len dependent 3x3 steps; once per LM iteration); each step
+// reads one 128-byte record.
+//  * The records do not depend on the recurrence: the loads of the next PF steps are kept in flight while a step computes
+//    (a ring of PF records in registers), so the chain is paced by the 3x3 arithmetic, not by a memory round trip per step.
+//  * The factor planes are transposed for the APPLY kernels (step k of all 64 lanes = one 512-byte access), which makes
+//    this thread's own 15 values per step land 8 bytes apiece in 15 different lines -- 468 MB written for 120 MB of
+//    factors at 1M poses.  So the results of GS = 8 consecutive steps are kept in registers and flushed together: in the
+//    transposed layout the values of poses j, j + CHUNK, j + 2 CHUNK, ... of one segment are adjacent, i.e. GS / CHUNK
+//    consecutive doubles per (plane, k) -- 32-byte (CHUNK = 2) or 16-byte (CHUNK = 4) pieces instead of 8-byte ones.
+template <int CHUNK>
+__global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len,
+                                                     double* __restrict__ cw, double* __restrict__ cs) {
+  constexpr int PF = 4, GS = 8, RUN = GS / CHUNK;   // RUN adjacent doubles per (plane, k) and group
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = n_loc, np = n_pad;
   const int64_t s0 = (int64_t)seg * seg_len;
@@ -1401,18 +1433,20 @@ __global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ 
     for (int c = 0; c < 8; ++c) ring[k][c] = in[c];
   }
   double p00 = 0.0, p01 = 0.0, p02 = 0.0, p11 = 0.0, p12 = 0.0, p22 = 0.0;  // S_{i-1}^-1
-  for (int64_t ib = s0; ib < s1; ib += PF) {
+  for (int64_t ib = s0; ib < s1; ib += GS) {
+    double OUT[GS][15];   // W (9) | S^-1 (6) of the group's steps
 #pragma unroll
-    for (int k = 0; k < PF; ++k) {
+    for (int k = 0; k < GS; ++k) {
       const int64_t i = ib + k;
       if (i < s1) {
-        const double2 v0 = ring[k][0], v1 = ring[k][1], v2 = ring[k][2], v3 = ring[k][3], v4 = ring[k][4], v5 = ring[k][5],
-                      v6 = ring[k][6], v7 = ring[k][7];
+        const int slot = k % PF;
+        const double2 v0 = ring[slot][0], v1 = ring[slot][1], v2 = ring[slot][2], v3 = ring[slot][3], v4 = ring[slot][4],
+                      v5 = ring[slot][5], v6 = ring[slot][6], v7 = ring[slot][7];
         {  // refill this slot with the record PF steps ahead
           const int64_t j = i + PF < s1 ? i + PF : s1 - 1;
           const double2* in = reinterpret_cast<const double2*>(rec + j * CHAIN_REC);
 #pragma unroll
-          for (int c = 0; c < 8; ++c) ring[k][c] = in[c];
+          for (int c = 0; c < 8; ++c) ring[slot][c] = in[c];
         }
         double a00 = v0.x, a01 = v0.y, a02 = v1.x, a11 = v1.y, a12 = v2.x, a22 = v2.y;
         double W[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1432,9 +1466,6 @@ __global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ 
           a12 -= W[3] * C[6] + W[4] * C[7] + W[5] * C[8];
           a22 -= W[6] * C[6] + W[7] * C[7] + W[8] * C[8];
         }
-        const int64_t ti = chain_tidx_g(i, chunk);  // chunk = 4: chain_tidx
-#pragma unroll
-        for (int c = 0; c < 9; ++c) cw[(int64_t)c * np + ti] = W[c];
         const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
         const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
         p00 = c00 * id;
@@ -1443,12 +1474,36 @@ __global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ 
         p11 = (a00 * a22 - a02 * a02) * id;
         p12 = (a01 * a02 - a00 * a12) * id;
         p22 = (a00 * a11 - a01 * a01) * id;
-        cs[ti] = p00;
-        cs[np + ti] = p01;
-        cs[2 * np + ti] = p02;
-        cs[3 * np + ti] = p11;
-        cs[4 * np + ti] = p12;
-        cs[5 * np + ti] = p22;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) OUT[k][c] = W[c];
+        OUT[k][9] = p00; OUT[k][10] = p01; OUT[k][11] = p02; OUT[k][12] = p11; OUT[k][13] = p12; OUT[k][14] = p22;
+      }
+    }
+    // ---- flush the group
+    if (ib + GS <= s1 && (ib % GS) == 0) {
+      // whole aligned group: pose ib + kk + CHUNK m (m < RUN) sits at chain_tidx_g(ib + kk) + m -- RUN adjacent doubles
+#pragma unroll
+      for (int kk = 0; kk < CHUNK; ++kk) {
+        const int64_t ti = chain_tidx_g(ib + kk, CHUNK);
+#pragma unroll
+        for (int c = 0; c < 15; ++c) {
+          double* dst = (c < 9 ? cw + (int64_t)c * np : cs + (int64_t)(c - 9) * np) + ti;
+#pragma unroll
+          for (int m = 0; m < RUN; m += 2)
+            *reinterpret_cast<double2*>(dst + m) = make_double2(OUT[kk + CHUNK * m][c], OUT[kk + CHUNK * (m + 1)][c]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < GS; ++k) {
+        const int64_t i = ib + k;
+        if (i < s1) {
+          const int64_t ti = chain_tidx_g(i, CHUNK);
+#pragma unroll
+          for (int c = 0; c < 9; ++c) cw[(int64_t)c * np + ti] = OUT[k][c];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) cs[(int64_t)c * np + ti] = OUT[k][9 + c];
+        }
       }
     }
   }

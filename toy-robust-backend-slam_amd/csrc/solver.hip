@@ -107,6 +107,8 @@ struct pgo_handle {
   int chain_scan = 0;                    // > 0: the lean apply runs its recurrence as this many scan levels (few long segments)
   int chain_nw = 4;                      // wavefronts per workgroup of the lean kernels: 1 on small graphs (a tile per CU)
   double *chain_c = nullptr, *chain_w = nullptr, *chain_s = nullptr;
+  int32_t* chain_dup_rows = nullptr;   // rows whose block (i, i-1) sums several edges (k_chain_dupfix)
+  int n_chain_dup = 0;
   // halo exchange of the search direction (world > 1, opt.halo_exchange)
   bool use_halo = false;
   int32_t *halo_send_rows = nullptr, *halo_recv_rows = nullptr;
@@ -344,6 +346,8 @@ struct pgo_handle {
     A.sw_gamma = sw_gamma;
     A.diag_full = diag_full;
     A.gs_full = gs_full;
+    A.chain_rec = chain_len ? chain_c : nullptr;
+    A.chain_seg = chain_len ? chain_len : 1;
     return A;
   }
   int assemble_enqueue() {
@@ -351,7 +355,13 @@ struct pgo_handle {
     if (has_sw) hipLaunchKernelGGL((dev::k_assemble<true, false>), dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
     else if (info_mode) hipLaunchKernelGGL((dev::k_assemble<false, true>), dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
     else hipLaunchKernelGGL((dev::k_assemble<false, false>), dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
-    return check_launch("k_assemble");
+    PGOC(check_launch("k_assemble"));
+    if (chain_len && n_chain_dup > 0) {
+      hipLaunchKernelGGL(dev::k_chain_dupfix, dim3((n_chain_dup + 63) / 64), dim3(64), 0, stream, (const int32_t*)chain_dup_rows, n_chain_dup,
+                         (const int32_t*)inc_ptr, (const int32_t*)inc_col, (const double*)hoff, S.lo, chain_c);
+      PGOC(check_launch("k_chain_dupfix"));
+    }
+    return PGO_OK;
   }
 
   // ---- K3
@@ -712,7 +722,22 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   }
   if (chain_len && NL > 0) {
     chain_pad = (int)(((NL + dev::CHAIN_TILE - 1) / dev::CHAIN_TILE) * dev::CHAIN_TILE);
-    PGOC(dalloc(&chain_c, (int64_t)dev::CHAIN_REC * NL));
+    PGOC(dalloc(&chain_c, (int64_t)dev::CHAIN_REC * NL));   // zero-filled: rows without a block (i, i-1) keep C = 0
+    {
+      std::vector<int32_t> dup;
+      for (int32_t r = 1; r < S.n_loc; ++r) {
+        if ((r % chain_len) == 0) continue;
+        int cnt = 0;
+        for (int32_t q = S.inc_ptr[r]; q < S.inc_ptr[r + 1]; ++q) cnt += (S.inc_col[q] == S.lo + r - 1);
+        if (cnt > 1) dup.push_back(r);
+      }
+      n_chain_dup = (int)dup.size();
+      if (n_chain_dup) {
+        PGOC(dalloc(&chain_dup_rows, n_chain_dup));
+        PGOC(upload(chain_dup_rows, dup));
+        PGOC(sync());  // `dup` dies with this scope
+      }
+    }
     PGOC(dalloc(&chain_w, 9 * (int64_t)chain_pad));
     PGOC(dalloc(&chain_s, 6 * (int64_t)chain_pad));
     // the padding rows of the factor planes are never written: they must read as 0
@@ -1118,7 +1143,7 @@ int pgo_handle::lm_iteration(bool* stop) {
 int pgo_handle::prepare_system() {
   hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, (const double*)diag_full, S.n_loc, S.lo, fixed_internal, radius,
                      opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv, (const uint8_t*)fixed_mask, (const int32_t*)prob_of_256,
-                     (const double*)prob_radius);
+                     (const double*)prob_radius, chain_len ? chain_c : (double*)nullptr);
   PGOC(check_launch("k_prepare"));
   if (grp_B > 1) {
     dev::GroupPrepArgs GA;
@@ -1136,13 +1161,14 @@ int pgo_handle::prepare_system() {
     hipLaunchKernelGGL(dev::k_prepare_groups, dim3(grp_prep_grid), dim3(dev::WG), grp_lds, stream, GA);
     PGOC(check_launch("k_prepare_groups"));
   }
-  if (chain_len) {
-    hipLaunchKernelGGL(dev::k_chain_extract, dim3(g_rows), dim3(dev::WG), 0, stream, (const int32_t*)inc_ptr, (const int32_t*)inc_col,
-                       (const double*)hoff, (const double*)hd, (const double*)d2, S.n_loc, S.lo, chain_len, chain_c);
-    PGOC(check_launch("k_chain_extract"));
+  if (chain_len) {   // (the records are complete: C part from k_assemble, M part from k_prepare)
     const int n_seg = (S.n_loc + chain_len - 1) / chain_len;
-    hipLaunchKernelGGL(dev::k_chain_factor, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc,
-                       chain_pad, chain_len, chain_chunk ? chain_chunk : dev::CHAIN_CHUNK, chain_w, chain_s);
+    if ((chain_chunk ? chain_chunk : dev::CHAIN_CHUNK) == 2)
+      hipLaunchKernelGGL(dev::k_chain_factor<2>, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
+                         chain_len, chain_w, chain_s);
+    else
+      hipLaunchKernelGGL(dev::k_chain_factor<4>, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
+                         chain_len, chain_w, chain_s);
     PGOC(check_launch("k_chain_factor"));
   }
   return PGO_OK;
@@ -2186,7 +2212,8 @@ int pgo_bench_assemble(pgo_t* h, int reps, pgo_kernel_stats* out) {
   out->units = h->S.n_edges_local;
   // every record read once (112 B/edge); per incidence 8 B indices + 72 B block written; per row 72 B out + 4 B
   // pointer + 24 B scale
-  out->algorithmic_bytes = 112.0 * h->S.n_edges_local + 80.0 * (double)h->S.n_inc + 100.0 * h->S.n_loc;
+  // chain preconditioner: + the 72-byte block (i, i-1) per row into the factorisation's input record
+  out->algorithmic_bytes = 112.0 * h->S.n_edges_local + 80.0 * (double)h->S.n_inc + (100.0 + (h->chain_len ? 72.0 : 0.0)) * h->S.n_loc;
   return PGO_OK;
 }
 
