@@ -143,7 +143,8 @@ struct pgo_handle {
   // captured slice of PCG iterations (world == 1)
   hipGraphExec_t cg_graph_exec = nullptr;
   int cg_graph_len = 0;
-  bool graph_failed = false, graph_collectives = true;
+  bool graph_failed = false;
+  int graph_collectives = 1;   // PGO_GRAPH_COLLECTIVES: 0 = never capture collectives, 1 = all-reduce / all-gather, 2 = also the p2p halo exchange
   int last_pcg_iters = 0;  // iteration count of the previous PCG solve of this handle (slice scheduling)
   // small graphs on one rank: the direction update rides in the next SpMV (k_spmv MODE 5) -- two launches per PCG
   // iteration instead of three; p_full / p_full2 alternate by iteration parity
@@ -536,7 +537,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   const char* fc = getenv("PGO_FORCE_COLLECTIVES");
   force_collectives = fc && fc[0] == '1';
   if (const char* nt = getenv("PGO_SPMV_NT")) spmv_nt = atoi(nt);
-  if (const char* gc = getenv("PGO_GRAPH_COLLECTIVES")) graph_collectives = gc[0] != '0';
+  if (const char* gc = getenv("PGO_GRAPH_COLLECTIVES")) graph_collectives = atoi(gc);
   grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
   chain_len = pgo::resolve_chain_len(opt.pcg_chain_len, opt.pcg_block_poses, N, E, ia, ib);
   if (chain_len != 0 && (chain_len < dev::CHAIN_CHUNK || chain_len % dev::CHAIN_CHUNK != 0 || dev::CHAIN_TILE % chain_len != 0))
@@ -645,7 +646,10 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     std::vector<int4> desc((size_t)std::max(1, S.n_tiles()));
     std::vector<int32_t> order;
     const char* to = getenv("PGO_TILE_ORDER");
-    if (!(to && to[0] == '0') && S.n_tiles() >= 4096 && !batch_mode) pgo::compute_tile_order(S, &order);  // (a batch keeps each problem's tiles together)
+    // OFF by default: it cuts the gather traffic (FETCH_SIZE 992 -> 920-937 MB at 1M poses) but the scattered 18-KB
+    // H chunks cost more than that saves (184 vs 179 us); PGO_TILE_ORDER=1 turns it on (never in a batch, which keeps
+    // each problem's tiles together)
+    if (to && to[0] == '1' && S.n_tiles() >= 4096 && !batch_mode) pgo::compute_tile_order(S, &order);
     for (int k = 0; k < S.n_tiles(); ++k) {
       const int t = order.empty() ? k : order[k];
       const int32_t r0 = S.tile_row[t], r1 = S.tile_row[t + 1];
@@ -1035,7 +1039,11 @@ int pgo_handle::pcg(int* iters, double* rel) {
   // -- otherwise every PCG iteration costs the host ~7 kernel launches + 3 collective calls, about the device time of
   // an iteration at 8 shards of the 1M-pose graph.  PGO_GRAPH_COLLECTIVES=0 keeps the eager loop; a capture that fails
   // falls back to it for the rest of the handle's life.
-  bool use_graph = opt.use_graphs && !graph_failed && (!multi || (comm->capturable() && !overlap && graph_collectives));
+  // The point-to-point halo exchange (an ncclSend / ncclRecv group) is NOT captured by default: it has never run against
+  // a real peer (no multi-GPU lease yet), and a group of p2p calls inside a graph is the less travelled road -- its
+  // first execution should be the plain one.  PGO_GRAPH_COLLECTIVES=2 captures it too.
+  bool use_graph = opt.use_graphs && !graph_failed &&
+                   (!multi || (comm->capturable() && !overlap && graph_collectives > 0 && (!use_halo || graph_collectives > 1)));
   if (use_graph) {
     every += every & 1;
     if (!cg_graph_exec || cg_graph_len != every) {
