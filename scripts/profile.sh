@@ -18,3 +18,5 @@ find $OUT -name "*.csv" | xargs ls -la
 # keep the merge-back small: drop the per-dispatch trace (tens of MB), keep stats + counters
 python3 scripts/summarize_profile.py $OUT $TAG && find $OUT -name "*kernel_trace.csv" -size +8M -delete
 tail -3 $OUT/trace.log
+# the summaries travel back through gpurun_out/ (the only directory merged into the caller's tree)
+mkdir -p gpurun_out/profiles && cp profiles/${TAG}_* profiles/pmc_traffic.json gpurun_out/profiles/ 2>/dev/null
