@@ -259,8 +259,9 @@ def main():
             "seconds": {"generate": t_gen, "create": t_create, "eval": summ.seconds_eval,
                         "assemble": summ.seconds_assemble, "linear": summ.seconds_linear,
                         "candidate": summ.seconds_candidate},
-            "handle": {k: v for k, v in info.as_dict().items() if k in ("pcg_block_poses", "pcg_chain_len", "chain_kernel", "n_tiles",
-                                                                       "n_incidences", "halo_send_rows", "halo_recv_rows", "device_bytes")},
+            "handle": {k: v for k, v in s.info().as_dict().items() if k in ("pcg_block_poses", "pcg_chain_len", "chain_kernel", "n_tiles",
+                                                                           "n_incidences", "halo_send_rows", "halo_recv_rows", "device_bytes",
+                                                                           "host_enqueue_us_per_pcg_iter", "pcg_graph_replay")},
         }
         # HBM bytes per launch of k_spmv from the committed rocprofv3 --pmc passes -- only if they were taken on THESE
         # kernel sources (the file records a digest of them); otherwise null rather than a stale figure

@@ -324,6 +324,10 @@ typedef struct pgo_handle_info {
   int32_t halo_overlap;              /* resolved                                                                    */
   int64_t halo_send_rows, halo_recv_rows;
   int64_t device_bytes;              /* HBM allocated by the handle                                                 */
+  double  host_enqueue_us_per_pcg_iter; /* host time spent in launch calls per enqueued PCG iteration so far (no waiting);
+                                        with graph replay ~0, eager multi-rank loops: launches + collective calls          */
+  int32_t pcg_graph_replay;          /* 1 = the PCG slices are replayed from a captured hipGraph                    */
+  int32_t _pad;
 } pgo_handle_info;
 int pgo_get_info(const pgo_t* h, pgo_handle_info* out);                           /* [host] */
 

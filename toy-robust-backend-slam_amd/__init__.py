@@ -102,7 +102,8 @@ class HandleInfo(C.Structure):
                 ("n_incidences", C.c_int64), ("pcg_block_poses", C.c_int32), ("pcg_chain_len", C.c_int32),
                 ("chain_kernel", C.c_int32), ("pose_ordering", C.c_int32), ("halo_exchange", C.c_int32),
                 ("halo_overlap", C.c_int32), ("halo_send_rows", C.c_int64), ("halo_recv_rows", C.c_int64),
-                ("device_bytes", C.c_int64)]
+                ("device_bytes", C.c_int64), ("host_enqueue_us_per_pcg_iter", C.c_double), ("pcg_graph_replay", C.c_int32),
+                ("_pad", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -146,6 +146,8 @@ struct pgo_handle {
   bool graph_failed = false;
   int graph_collectives = 1;   // PGO_GRAPH_COLLECTIVES: 0 = never capture collectives, 1 = all-reduce / all-gather, 2 = also the p2p halo exchange
   int last_pcg_iters = 0;  // iteration count of the previous PCG solve of this handle (slice scheduling)
+  double t_enqueue = 0.0;  // host seconds spent enqueueing PCG iterations (launch calls only, no waiting), and how many
+  int64_t n_enqueued = 0;
   // small graphs on one rank: the direction update rides in the next SpMV (k_spmv MODE 5) -- two launches per PCG
   // iteration instead of three; p_full / p_full2 alternate by iteration parity
   bool fused_p = false;
@@ -1088,6 +1090,8 @@ int pgo_handle::pcg(int* iters, double* rel) {
   int it = 0;
   int ahead = (last_pcg_iters > 0) ? std::max(1, (int)(0.85 * last_pcg_iters) / every) : 1;
   while (true) {
+    const double te0 = wall_s();
+    const int it_before = it;
     for (int sl = 0; sl < ahead && it < max_it; ++sl) {
       const int chunk = std::min(every, max_it - it);
       if (use_graph && chunk == every && (it & 1) == 0) {
@@ -1102,6 +1106,8 @@ int pgo_handle::pcg(int* iters, double* rel) {
       it += chunk;
     }
     ahead = 1;
+    t_enqueue += wall_s() - te0;
+    n_enqueued += it - it_before;
     HIPC(hipMemcpyAsync(h_st, st, sizeof(dev::CgState), hipMemcpyDeviceToHost, stream));
     PGOC(sync());
     if (h_st->done || it >= max_it) break;
@@ -1670,6 +1676,8 @@ int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   out->halo_send_rows = (int64_t)h->S.halo_send_row.size();
   out->halo_recv_rows = (int64_t)h->S.halo_recv_row.size();
   out->device_bytes = h->device_bytes;
+  out->host_enqueue_us_per_pcg_iter = h->n_enqueued > 0 ? 1e6 * h->t_enqueue / (double)h->n_enqueued : 0.0;
+  out->pcg_graph_replay = (h->cg_graph_exec != nullptr && !h->graph_failed) ? 1 : 0;
   return PGO_OK;
 }
 
