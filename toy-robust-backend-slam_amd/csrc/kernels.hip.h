@@ -858,6 +858,103 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   if (tid == 0) A.dot_part[blockIdx.x] = tot;
 }
 
+// ------------------------------------------------------------------- K3, software-pipelined form
+// The same product (single-rank product kernel: MODE 0 of k_spmv_t, tiles of <= 256 incidences only) with the loads of
+// tile t + 1 -- block stream, gathers, row operands -- issued BEFORE the barrier and the row phase of tile t, so that a
+// workgroup always has a tile's worth of memory requests in flight instead of waiting out one round trip per tile.
+// Costs registers (two tiles' operands live: ~110 VGPRs, 4 workgroups per CU instead of 8) -- the same bytes in flight.
+__global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
+  __shared__ double scr[2][3][WG];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  if (A.done && *A.done) return;
+  const int64_t n = A.n_loc;
+  const XcdRange xr = xcd_range(A.n_tiles);
+  struct Lane {
+    double h[9], p0, p1, p2;     // lane phase: block + gathered direction
+    double h0, h1, h2, dd, pr0, pr1, pr2;   // row phase: diagonal row, LM diagonal, own direction
+    int a, row, lo, hi;
+    bool on, pv;
+  };
+  auto issue = [&](const int4& d, int col_) {
+    Lane L;
+    const int r0 = d.x, nrows = d.y, q0 = d.z, nq = d.w;
+    L.pv = tid < nrows * 3;
+    L.a = 0; L.row = r0; L.lo = 0; L.hi = 0;
+    L.h0 = L.h1 = L.h2 = L.dd = L.pr0 = L.pr1 = L.pr2 = 0.0;
+    if (L.pv) {
+      L.a = tid / nrows;
+      L.row = r0 + (tid - L.a * nrows);
+      L.lo = A.inc_ptr[L.row] - q0;
+      L.hi = A.inc_ptr[L.row + 1] - q0;
+      const int a = L.a;
+      const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
+      L.h0 = ld_stream(A.hd + ((int64_t)a * n + L.row));
+      L.h1 = ld_stream(A.hd + ((int64_t)i1 * n + L.row));
+      L.h2 = ld_stream(A.hd + ((int64_t)i2 * n + L.row));
+      if (A.with_d2) L.dd = ld_stream(A.d2 + (3 * (int64_t)L.row + a));
+      gather3(A.p, (int64_t)A.lo + L.row, L.pr0, L.pr1, L.pr2);
+    }
+    L.on = tid < nq;
+    L.p0 = L.p1 = L.p2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) L.h[c] = 0.0;
+    if (L.on) {
+      gather3(A.p, (int64_t)col_, L.p0, L.p1, L.p2);
+      if (A.nt) hoff_load_nt(A.hoff, q0 + tid, L.h);
+      else hoff_load(A.hoff, q0 + tid, L.h);
+    }
+    return L;
+  };
+  double dot = 0.0;
+  int buf = 0;
+  int t = xr.begin;
+  if (t < xr.end) {
+    int4 d0 = A.tile_desc[t];
+    int col0 = (tid < d0.w) ? A.inc_col[d0.z + tid] : 0;
+    Lane L = issue(d0, col0);
+    // descriptor and column indices of the tile after: one iteration ahead of their use
+    int4 d1 = d0;
+    int col1 = 0;
+    if (t + xr.step < xr.end) {
+      d1 = A.tile_desc[t + xr.step];
+      col1 = (tid < d1.w) ? ld_stream(A.inc_col + d1.z + tid) : 0;
+    }
+    for (; t < xr.end; t += xr.step) {
+      const int tn = t + xr.step, tnn = tn + xr.step;
+      int4 d2 = d1;
+      if (tnn < xr.end) d2 = A.tile_desc[tnn];
+      // stage tile t
+      if (L.on) {
+        scr[buf][0][tid] = L.h[0] * L.p0 + L.h[1] * L.p1 + L.h[2] * L.p2;
+        scr[buf][1][tid] = L.h[3] * L.p0 + L.h[4] * L.p1 + L.h[5] * L.p2;
+        scr[buf][2][tid] = L.h[6] * L.p0 + L.h[7] * L.p1 + L.h[8] * L.p2;
+      }
+      // row operands of tile t stay; everything of tile t + 1 goes out now
+      const bool pv = L.pv;
+      const int a = L.a, row = L.row, lo = L.lo, hi = L.hi;
+      const double h0 = L.h0, h1 = L.h1, h2 = L.h2, dd = L.dd, pr0 = L.pr0, pr1 = L.pr1, pr2 = L.pr2;
+      if (tn < xr.end) L = issue(d1, col1);
+      int col2 = 0;
+      if (tnn < xr.end) col2 = (tid < d2.w) ? ld_stream(A.inc_col + d2.z + tid) : 0;
+      __syncthreads();
+      if (pv) {
+        double s = 0.0;
+        for (int j = lo; j < hi; ++j) s += scr[buf][a][j];
+        const double pa = (a == 0) ? pr0 : (a == 1 ? pr1 : pr2);
+        s += h0 * pr0 + h1 * pr1 + h2 * pr2 + dd * pa;
+        st_stream(A.y + (3 * (int64_t)row + a), s);
+        dot += pa * s;
+      }
+      buf ^= 1;
+      d1 = d2;
+      col1 = col2;
+    }
+  }
+  const double tot = block_sum_bcast(dot, red);
+  if (tid == 0) A.dot_part[blockIdx.x] = tot;
+}
+
 // The blocks whose column lives on another rank (a few % of a shard's incidences, listed per row at create): after the
 // halo exchange, y_row += sum H_rc p_c and the matching part of p . A p.  One thread per row that has such blocks.
 struct RemoteArgs {

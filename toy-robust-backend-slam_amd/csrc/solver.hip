@@ -83,6 +83,7 @@ struct pgo_handle {
   int64_t n_edges_total = 0;
   int32_t *inc_ptr = nullptr, *inc_edge = nullptr, *inc_col = nullptr, *tile_row = nullptr;
   int4* tile_desc = nullptr;
+  bool spmv_pipe = false;   // software-pipelined K3 (k_spmv_p): when no tile is a chunked heavy row or has > 85 rows
   int64_t inc_stride = 0;
   // normal equations
   double *hoff = nullptr, *hd = nullptr, *gs = nullptr, *d2 = nullptr, *minv = nullptr;
@@ -400,7 +401,9 @@ struct pgo_handle {
       case 1: hipLaunchKernelGGL(dev::k_spmv_t<1>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
       case 2: hipLaunchKernelGGL(dev::k_spmv_t<2>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
       case 3: hipLaunchKernelGGL(dev::k_spmv_t<3>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
-      default: hipLaunchKernelGGL(dev::k_spmv_t<0>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+      default:
+        if (spmv_pipe) hipLaunchKernelGGL(dev::k_spmv_p, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+        else hipLaunchKernelGGL(dev::k_spmv_t<0>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
     }
     return check_launch("k_spmv");
   }
@@ -618,7 +621,8 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   g_edge = up8(std::max(1, cdiv(EL, dev::WG)));
   g_rows = std::max(1, cdiv(NL, dev::WG));
   g_vec = std::min(std::max(1, cdiv(NL, dev::WG)), 1024);
-  g_flat = std::min(std::max(1, cdiv(3 * NL, dev::WG)), 2048);
+  g_flat = std::min(std::max(1, cdiv(3 * NL, dev::WG)), 1024);
+  if (const char* fe = getenv("PGO_FLAT_GRID")) g_flat = std::min(g_flat, std::max(8, atoi(fe)));
   g_spmv = up8(std::min(std::max(1, S.n_tiles()), 2048));
   g_asm = up8(std::min(std::max(1, S.n_tiles()), 1 << 20));
   part_cap = std::max(g_edge, 2048) + 8;
@@ -656,6 +660,21 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       const int t = order.empty() ? k : order[k];
       const int32_t r0 = S.tile_row[t], r1 = S.tile_row[t + 1];
       desc[k] = make_int4(r0, r1 - r0, S.inc_ptr[r0], S.inc_ptr[r1] - S.inc_ptr[r0]);
+    }
+    {
+      // the software-pipelined product kernel (k_spmv_p) needs plain tiles: no chunked heavy row, at most 85 rows
+      // (one row-phase pass); PGO_SPMV_PIPE=0 keeps k_spmv_t.  Measured on one box at 1M poses: k_spmv_t 185.7 us (8
+      // workgroups per CU), k_spmv_p 172.4 / 175.5 / 168.8 / 165.1 us at 8 / 6 / 5 / 4 workgroups per CU.
+      const char* pe = getenv("PGO_SPMV_PIPE");
+      bool ok = !(pe && pe[0] == '0');
+      for (int t = 0; ok && t < S.n_tiles(); ++t)
+        ok = desc[t].w <= dev::WG && desc[t].y * 3 <= dev::WG;
+      spmv_pipe = ok;
+      if (ok) {
+        int per_cu = 4;
+        if (const char* ge = getenv("PGO_SPMV_PIPE_WGS")) per_cu = std::max(1, atoi(ge));
+        g_spmv = ((std::min(std::max(1, S.n_tiles()), 256 * per_cu) + 7) / 8) * 8;
+      }
     }
     PGOC(dalloc(&tile_desc, (int64_t)desc.size()));
     PGOC(upload(tile_desc, desc));
@@ -774,7 +793,12 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       if (const char* cs = getenv("PGO_CHAIN_SCAN")) {  // experiments: 0 = always serial
         if (atoi(cs) == 0) chain_scan = 0;
       }
-      g_chain = (int)std::min<int64_t>((n_wt + chain_nw - 1) / chain_nw, 2048);
+      // every workgroup of the NEXT kernel re-sums this kernel's per-workgroup partials, so fewer, longer-running
+      // workgroups are cheaper all round: 2048 -> 512 (and 1024 for the flat vector kernels) 25.43 -> 24.65 ms per LM
+      // iteration at 1M poses (same box, 3 interleaved repetitions)
+      int cap = 512;
+      if (const char* ce = getenv("PGO_CHAIN_GRID")) cap = std::max(8, atoi(ce));
+      g_chain = (int)std::min<int64_t>((n_wt + chain_nw - 1) / chain_nw, cap);
     }
   } else {
     chain_len = 0;
