@@ -785,7 +785,9 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       // its own CU's L1, and -- for segments of more than 16 lanes -- the recurrence as a log-depth scan (INTEL, 256-pose
       // segments: 7.4 -> 4.8 us per apply); large graphs keep the 4-wave workgroups and the serial DPP recurrence,
       // which needs fewer registers and no LDS-crossbar shuffles.
-      const bool small = n_wt <= 512;
+      int64_t small_max = 512;
+      if (const char* sm = getenv("PGO_CHAIN_SMALL_TILES")) small_max = atoll(sm);
+      const bool small = n_wt <= small_max;
       chain_nw = small ? 1 : 4;
       chain_scan = 0;
       if (small && chain_len / chain_chunk > 16)
@@ -798,7 +800,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       // iteration at 1M poses (same box, 3 interleaved repetitions)
       int cap = 512;
       if (const char* ce = getenv("PGO_CHAIN_GRID")) cap = std::max(8, atoi(ce));
-      g_chain = (int)std::min<int64_t>((n_wt + chain_nw - 1) / chain_nw, cap);
+      g_chain = (int)std::min<int64_t>((n_wt + chain_nw - 1) / chain_nw, chain_nw == 1 ? 2048 : cap);
     }
   } else {
     chain_len = 0;
@@ -836,7 +838,9 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   }
   {
     const char* fe = getenv("PGO_FUSED_P");
-    fused_p = !(fe && fe[0] == '0') && world == 1 && !force_collectives && !batch_mode && NL > 0 && NL <= 16384;
+    int64_t fused_max = 16384;
+    if (const char* fm = getenv("PGO_FUSED_MAX_ROWS")) fused_max = atoll(fm);
+    fused_p = !(fe && fe[0] == '0') && world == 1 && !force_collectives && !batch_mode && NL > 0 && NL <= fused_max;
     if (fused_p) PGOC(dalloc(&p_full2, dev::PS * n_full));
   }
   if (!fixed_mask_h.empty()) {
