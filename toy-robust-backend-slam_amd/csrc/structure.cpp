@@ -174,17 +174,34 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
 
   // local edges, sorted by (min endpoint, max endpoint, original index): pose
   // gathers of consecutive lanes then walk the pose array almost sequentially
+  // (a counting sort on the smaller endpoint, then the handful of edges per bucket by (larger endpoint, index): the
+  // comparison sort of the 4M edges of the 1M-pose graph was half of the symbolic phase)
   std::vector<int32_t> loc;
-  loc.reserve(world == 1 ? E : (size_t)(2.2 * E / world) + 16);
-  for (int32_t e = 0; e < E; ++e)
-    if (owned(ia[e]) || owned(ib[e])) loc.push_back(e);
-  std::sort(loc.begin(), loc.end(), [&](int32_t x, int32_t y) {
-    int32_t xm = std::min(ia[x], ib[x]), ym = std::min(ia[y], ib[y]);
-    if (xm != ym) return xm < ym;
-    int32_t xM = std::max(ia[x], ib[x]), yM = std::max(ia[y], ib[y]);
-    if (xM != yM) return xM < yM;
-    return x < y;
-  });
+  {
+    std::vector<int32_t> cnt((size_t)N + 1, 0);
+    int64_t n_loc_e = 0;
+    for (int32_t e = 0; e < E; ++e)
+      if (owned(ia[e]) || owned(ib[e])) {
+        cnt[(size_t)std::min(ia[e], ib[e]) + 1]++;
+        ++n_loc_e;
+      }
+    for (int32_t i = 0; i < N; ++i) cnt[(size_t)i + 1] += cnt[i];
+    loc.resize((size_t)n_loc_e);
+    {
+      std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
+      for (int32_t e = 0; e < E; ++e)   // ascending e: equal keys stay in index order
+        if (owned(ia[e]) || owned(ib[e])) loc[(size_t)fill[std::min(ia[e], ib[e])]++] = e;
+    }
+    for (int32_t i = 0; i < N; ++i) {
+      const int32_t b = cnt[i], en = cnt[(size_t)i + 1];
+      if (en - b < 2) continue;
+      std::sort(loc.begin() + b, loc.begin() + en, [&](int32_t x, int32_t y) {
+        const int32_t xM = std::max(ia[x], ib[x]), yM = std::max(ia[y], ib[y]);
+        if (xM != yM) return xM < yM;
+        return x < y;
+      });
+    }
+  }
   const int32_t EL = (int32_t)loc.size();
   S->n_edges_local = EL;
   S->orig_edge = loc;
@@ -240,10 +257,11 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
     }
     // order each row's incidences by column (deterministic accumulation order
     // that does not depend on the sharding)
+    std::vector<std::pair<int32_t, int32_t>> tmp;   // one buffer for all rows
     for (int32_t i = 0; i < S->n_loc; ++i) {
       int32_t b = ptr[i], e = ptr[i + 1];
       if (e - b < 2) continue;
-      std::vector<std::pair<int32_t, int32_t>> tmp(e - b);
+      tmp.resize((size_t)(e - b));
       for (int32_t q = b; q < e; ++q) tmp[q - b] = {S->inc_col[q], S->inc_edge[q]};
       std::sort(tmp.begin(), tmp.end(), [&](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) {
         if (x.first != y.first) return x.first < y.first;
