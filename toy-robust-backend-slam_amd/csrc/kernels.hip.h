@@ -1248,10 +1248,19 @@ __global__ __launch_bounds__(WG) void k_cg_update2(CgVec V, int parity, const do
   const double beta = rz_new / rz_old;
   const int64_t n3 = 3 * (int64_t)V.n_loc;
   double* p = V.p + PS * (int64_t)V.lo;
-  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n3; i += (int64_t)gridDim.x * WG) {
-    const int64_t row = i / 3, j = PS * row + (i - 3 * row);
-    p[j] = ld_stream(V.z + i) + beta * p[j];
+  static_assert(PS == 3, "the owned part of the gather vector is contiguous");
+  // 16 bytes per lane (the vectors are 8-byte aligned only: p starts at 3 * lo doubles)
+  const int64_t n2 = n3 >> 1;
+  double2_a8* p2 = reinterpret_cast<double2_a8*>(p);
+  const double2_a8* z2 = reinterpret_cast<const double2_a8*>(V.z);
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n2; i += (int64_t)gridDim.x * WG) {
+    const double2_a8 zv = __builtin_nontemporal_load(z2 + i), pv = p2[i];
+    double2_a8 o;
+    o.x = zv.x + beta * pv.x;
+    o.y = zv.y + beta * pv.y;
+    p2[i] = o;
   }
+  if ((n3 & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n3 - 1] = V.z[n3 - 1] + beta * p[n3 - 1];
 }
 
 // ------------------------------------------------- block-Jacobi with blocks of B poses
@@ -2431,6 +2440,32 @@ __global__ void k_accept_rows(int n_loc, int lo, const int32_t* __restrict__ pro
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / 3);
     if (accept[prob_of_256[row >> 8]]) x[3 * (int64_t)lo + i] = cand[3 * (int64_t)lo + i];
+  }
+}
+
+// Model decrease without a product by H: PCG leaves r = b - (H + D) y (its recurrence residual), so
+//     y.(H y) = y.b - y.r - y.(D y)
+// -- three dot products over vectors that are there anyway instead of one more SpMV per LM iteration.  Partials of
+// y.b, y.r and y.(D y) per workgroup.
+__global__ __launch_bounds__(WG) void k_model_terms(int64_t n, const double* __restrict__ y, const double* __restrict__ b,
+                                                    const double* __restrict__ r, const double* __restrict__ d2,
+                                                    double* __restrict__ part_yb, double* __restrict__ part_yr,
+                                                    double* __restrict__ part_ydy) {
+  __shared__ double red[8];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) {
+    const double yi = y[i];
+    s0 += yi * b[i];
+    s1 += yi * r[i];
+    s2 += yi * yi * d2[i];
+  }
+  s0 = block_sum_bcast(s0, red);
+  s1 = block_sum_bcast(s1, red);
+  s2 = block_sum_bcast(s2, red);
+  if (threadIdx.x == 0) {
+    part_yb[blockIdx.x] = s0;
+    part_yr[blockIdx.x] = s1;
+    part_ydy[blockIdx.x] = s2;
   }
 }
 

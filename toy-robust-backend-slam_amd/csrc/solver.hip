@@ -1222,12 +1222,15 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
   R.pcg_rel_residual = rel;
   // model_cost_change = -(J d).(r + J d / 2), d = -S y   ==   y.gs - y.(H y) / 2
   if (!solo) {  // (the one-workgroup solve has done all of this in its epilogue; the gather vector holds y either way)
-    hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
-    PGOC(check_launch("k_scatter_owned"));
-    PGOC(share_gather_vector(p_full));
-    PGOC(spmv_enqueue(p_full, ap, part[0], 0, nullptr));  // part[0] <- partials of y.(H y)
-    hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs, part[1]);
-    PGOC(check_launch("k_dot"));
+    if (has_sw) {  // the switch back-substitution below reads y of both endpoints from the gather vector
+      hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
+      PGOC(check_launch("k_scatter_owned"));
+      PGOC(share_gather_vector(p_full));
+    }
+    // y.(H y) = y.b - y.r - y.(D y) from the PCG residual (no product by H): part[1] = y.b, part[0] = y.r, part[5] = y.(D y)
+    hipLaunchKernelGGL(dev::k_model_terms, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs,
+                       (const double*)r, (const double*)d2, part[1], part[0], part[5]);
+    PGOC(check_launch("k_model_terms"));
     // candidate x + d and |d|^2
     double* x_old = poses;
     hipLaunchKernelGGL(dev::k_candidate, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, x_old, scale, y, cand, part[3]);
@@ -1246,8 +1249,9 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
     h_scal[1] = h_solo->yHy;
     h_scal[2] = h_solo->step2;
   } else {
-    PGOC(reduce_to_scal({{part[1], g_flat, 0}, {part[0], g_spmv, 0}, {part[3], g_flat, 0}}, 0));
-    PGOC(fetch_scal(0, 3));
+    PGOC(reduce_to_scal({{part[1], g_flat, 0}, {part[0], g_flat, 0}, {part[3], g_flat, 0}, {part[5], g_flat, 0}}, 0));
+    PGOC(fetch_scal(0, 4));
+    h_scal[1] = h_scal[0] - h_scal[1] - h_scal[3];   // y.(H y)
   }
   if (has_sw) {
     PGOC(fetch_scal(13, 2));
