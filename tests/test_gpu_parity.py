@@ -233,6 +233,38 @@ def test_lm_solve_matches_golden(pgo, name, n_out, method):
     s.close()
 
 
+def test_product_kernels_agree(pgo, oracle, monkeypatch):
+    """K3 has two product kernels -- the software-pipelined k_spmv_p (plain tiles) and k_spmv_t (every other case) -- and
+    small graphs take the fused-direction-update loop (k_spmv_t MODE 5): the same product / the same solve from each"""
+    g = pgo.synth_manhattan(60000, 4.0, 0.10, 3)
+    x = np.random.default_rng(9).standard_normal(3 * g.n_poses)
+    ys = {}
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("PGO_SPMV_PIPE", pipe)
+        s = pgo.Solver(g, pgo.Options(method=1, max_iters=2, pcg_rtol=0.1, pcg_max_iters=100))
+        s.lm_begin()
+        s.lm_step(1)
+        ys[pipe] = s.spmv(x)
+        s.close()
+    monkeypatch.delenv("PGO_SPMV_PIPE")
+    assert np.abs(ys["1"] - ys["0"]).max() < 1e-11 * np.abs(ys["0"]).max()
+    og = oracle_graph(oracle, g)
+    # the fused loop against the three-kernel loop on a small graph: same iterates up to rounding
+    gi = load(pgo, "INTEL", 50)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PGO_FUSED_P", fused)
+        s = pgo.Solver(gi, pgo.Options(method=1, max_iters=6))
+        sm = s.solve()
+        out[fused] = (s.poses(), sm.total_pcg_iters, sm.final_cost)
+        s.close()
+    monkeypatch.delenv("PGO_FUSED_P")
+    assert out["1"][2] == pytest.approx(out["0"][2], rel=1e-10)
+    assert abs(out["1"][1] - out["0"][1]) <= 6          # PCG iterations over 6 LM iterations
+    assert np.abs(out["1"][0] - out["0"][0]).max() < 1e-8
+    assert og.n_poses == g.n_poses
+
+
 def test_duplicate_edges_are_summed_in_a_fixed_order(pgo, oracle):
     """several edges between the same two poses (CSAIL has one such pair; here every fifth odometry pair is tripled and
     every loop doubled) inside the dense pose-block preconditioner: the blocks of a pair are summed by ONE thread in the
