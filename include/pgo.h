@@ -179,6 +179,16 @@ typedef struct pgo_options {
                                   multiplies the blocks whose columns are owned; the blocks that need halo rows follow.
                                   Checked against the plain schedule with the host-staged test communicator only: the
                                   RCCL send/recv group has not yet run against a real peer                              */
+  int32_t linear_solver;       /* how (J'J + D'D) y = J'r is solved (the reference: SPARSE_NORMAL_CHOLESKY, main.cpp:154-163):
+                                  1 = block-Jacobi PCG to pcg_rtol;
+                                  2 = direct: the odometry chain (one edge per consecutive pose pair; block tridiagonal, factorised
+                                      exactly) + every other edge as a low-rank term through the Woodbury identity -- a dense
+                                      Cholesky of order 3 x (edges outside the chain) -- + iterative refinement.  One rank,
+                                      METHOD 0 / 1, a constant pose, every consecutive pose pair joined by an edge, at most 682
+                                      edges outside the chain, at most 16384 poses; else PGO_ERR_UNSUPPORTED;
+                                  0 (default) = auto: 2 where it applies (INTEL, MIT, CSAIL, FR079 ...) when pcg_rtol <= 1e-8
+                                      (the "exact" mode) and pcg_block_poses / pcg_chain_len are left at auto; else 1           */
+  int32_t _pad_opt;
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */
@@ -327,6 +337,8 @@ typedef struct pgo_handle_info {
   double  host_enqueue_us_per_pcg_iter; /* host time spent in launch calls per enqueued PCG iteration so far (no waiting);
                                         with graph replay ~0, eager multi-rank loops: launches + collective calls          */
   int32_t pcg_graph_replay;          /* 1 = the PCG slices are replayed from a captured hipGraph                    */
+  int32_t linear_solver;             /* resolved: 1 = PCG, 2 = direct (chain + low rank)                            */
+  int32_t direct_rank;               /* order of the direct solve's dense capacitance matrix (3 x edges outside the chain) */
   int32_t _pad;
 } pgo_handle_info;
 int pgo_get_info(const pgo_t* h, pgo_handle_info* out);                           /* [host] */

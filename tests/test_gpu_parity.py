@@ -202,15 +202,23 @@ CASES = [("INTEL", 50, 1), ("INTEL", 50, 0), ("INTEL", 0, 1), ("INTEL", 0, 0), (
          ("M3500", 184, 1), ("M3500", 184, 0), ("MIT", 2, 1), ("MIT", 2, 0)]
 
 
+DIRECT_OK = {"INTEL", "MIT", "CSAIL", "FR079"}   # chain-like: the direct (chain + low-rank) solve applies; M3500 / FRH: PCG
+
+
+@pytest.mark.parametrize("solver", [0, 1])
 @pytest.mark.parametrize("name,n_out,method", CASES)
-def test_lm_solve_matches_golden(pgo, name, n_out, method):
+def test_lm_solve_matches_golden(pgo, name, n_out, method, solver):
     """BASELINE configs C1-C3: full 50-iteration LM solve vs the oracle's direct-solve (SPARSE_NORMAL_CHOLESKY
-    stand-in) fixture.  north_star: final pose translations within 1e-4."""
+    stand-in) fixture.  north_star: final pose translations within 1e-4.  solver 0 = the library's choice (the direct
+    chain + low-rank solve on the chain-like datasets, PCG on M3500 / FRH), 1 = PCG to 1e-10 everywhere."""
+    if solver == 0 and name not in DIRECT_OK:
+        pytest.skip("auto = PCG on this dataset: covered by solver = 1")
     tag = "%s_out%d_m%d" % (name, n_out, method)
     fx = json.load(open(os.path.join(GOLDEN, "lm_%s.json" % tag)))
     ref = np.load(os.path.join(GOLDEN, "lm_%s_poses.npy" % tag))
     g = load(pgo, name, n_out)
-    s = pgo.Solver(g, pgo.Options(method=method, pcg_max_iters=200000))
+    s = pgo.Solver(g, pgo.Options(method=method, pcg_max_iters=200000, linear_solver=solver))
+    assert s.info().linear_solver == (2 if solver == 0 else 1)
     summ = s.solve()
     x = s.poses()
     assert summ.termination == fx["termination"] and summ.iterations == fx["iterations"]
@@ -218,7 +226,7 @@ def test_lm_solve_matches_golden(pgo, name, n_out, method):
     assert summ.final_cost == pytest.approx(fx["final_cost"], rel=1e-7)
     d_xy = np.abs(x[:, :2] - ref[:, :2]).max()
     d_th = np.abs(x[:, 2] - ref[:, 2]).max()
-    print(f"{tag}: max |d translation| {d_xy:.3e}  max |d theta| {d_th:.3e}  pcg iters {summ.total_pcg_iters}")
+    print(f"{tag} solver {s.info().linear_solver}: max |d translation| {d_xy:.3e}  max |d theta| {d_th:.3e}  pcg iters {summ.total_pcg_iters}  {summ.iterations / summ.seconds_total:.0f} GN it/s")
     assert d_xy < 1e-4 and d_th < 1e-4          # the north_star tolerance
     assert d_xy < 5e-6                          # what this implementation actually achieves
     recs = s.iter_records()
@@ -230,6 +238,84 @@ def test_lm_solve_matches_golden(pgo, name, n_out, method):
     # in-place semantics of the reference (Node::p)
     s.write_back()
     np.testing.assert_array_equal(g.poses, x)
+    s.close()
+
+
+# ----------------------------------------------------------------- direct (chain + low-rank) linear solve
+@pytest.mark.parametrize("name,n_out,method", [("INTEL", 50, 1), ("INTEL", 50, 0), ("CSAIL", 0, 1), ("FR079", 0, 0), ("MIT", 2, 1)])
+def test_direct_solve_agrees_with_pcg(pgo, name, n_out, method):
+    """linear_solver = 2 (odometry chain factorised exactly + every other edge through the Woodbury identity + iterative
+    refinement against the assembled block-CSR matrix) against linear_solver = 1 (PCG to 1e-12), LM iteration by LM
+    iteration: same accept / reject history, costs to 1e-9, and a residual |g - (H + D'D) y| / |g| far below PCG's"""
+    g = load(pgo, name, n_out)
+    out = {}
+    for ls in (2, 1):
+        s = pgo.Solver(g, pgo.Options(method=method, max_iters=12, linear_solver=ls, pcg_rtol=1e-12, pcg_max_iters=400000))
+        i = s.info()
+        assert i.linear_solver == ls and (i.direct_rank > 0) == (ls == 2)
+        sm = s.solve()
+        out[ls] = (s.iter_records(), s.poses(), sm)
+        s.close()
+    ra, rb = out[2][0], out[1][0]
+    assert len(ra) == len(rb)
+    for a, b in zip(ra, rb):
+        assert a["step_ok"] == b["step_ok"]
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-9)
+        assert a["pcg_iters"] == 0 and (a["iter"] == 0 or a["pcg_rel_residual"] < 1e-9)
+    d = np.abs(out[2][1] - out[1][1]).max()
+    print(f"{name}+{n_out} M{method}: direct vs PCG(1e-12) after 12 LM iterations max |d pose| {d:.2e}; "
+          f"{out[2][2].iterations / out[2][2].seconds_total:.0f} vs {out[1][2].iterations / out[1][2].seconds_total:.0f} GN it/s")
+    assert d < 1e-7 and out[2][2].total_pcg_iters == 0
+
+
+def test_direct_solve_eligibility(pgo):
+    """auto picks the direct solve only in the exact mode on chain-like graphs; forcing it elsewhere is an error, not a
+    silent fallback"""
+    gi = load(pgo, "INTEL", 50)
+    assert pgo.Solver(gi, pgo.Options(method=1)).info().linear_solver == 2
+    assert pgo.Solver(gi, pgo.Options(method=1, pcg_rtol=0.1)).info().linear_solver == 1          # inexact steps were asked for
+    assert pgo.Solver(gi, pgo.Options(method=1, pcg_chain_len=64)).info().linear_solver == 1      # the caller chose a preconditioner
+    assert pgo.Solver(gi, pgo.Options(method=2)).info().linear_solver == 1                        # switches: PCG
+    for name in ("M3500", "FRH"):                                                                  # too many edges outside the chain
+        g = load(pgo, name)
+        assert pgo.Solver(g, pgo.Options(method=1)).info().linear_solver == 1
+        with pytest.raises(pgo.PgoError) as e:
+            pgo.Solver(g, pgo.Options(method=1, linear_solver=2))
+        assert e.value.status == -8   # PGO_ERR_UNSUPPORTED
+    with pytest.raises(pgo.PgoError):
+        pgo.Solver(gi, pgo.Options(method=1, linear_solver=2, fixed_pose=-1))                      # nothing anchors the chain
+    with pytest.raises(pgo.PgoError):
+        pgo.Solver(gi, pgo.Options(method=1, linear_solver=7))
+
+
+def test_direct_solve_other_options_and_reproducibility(pgo, oracle):
+    """another constant pose, no loss, no Jacobi scaling -- against the oracle's sparse direct solve -- and bitwise
+    reproducibility of the direct path (every sum in a fixed order)"""
+    g = load(pgo, "CSAIL")
+    og = oracle_graph(oracle, g)
+    for kw in (dict(fixed_pose=17), dict(huber_delta=0.0), dict(jacobi_scaling=0)):
+        s = pgo.Solver(g, pgo.Options(method=1, max_iters=6, linear_solver=2, **kw))
+        summ = s.solve()
+        ores = oracle.lm_direct(og, oracle.Options(method=1, max_iters=6, **kw))
+        assert summ.final_cost == pytest.approx(ores.final_cost, rel=1e-9)
+        assert [r["step_ok"] for r in s.iter_records()] == [r["step_ok"] for r in ores.records]
+        assert np.abs(s.poses() - ores.poses).max() < 1e-7
+        s.close()
+    gi = load(pgo, "INTEL", 50)
+    runs = []
+    for _ in range(2):
+        s = pgo.Solver(gi, pgo.Options(method=1, max_iters=8, linear_solver=2))
+        s.solve()
+        runs.append(s.poses())
+        s.close()
+    np.testing.assert_array_equal(runs[0], runs[1])
+    # a graph without any edge outside the chain (pure odometry): rank 0, the chain factorisation alone is the solve
+    keep = [k for k in range(g.n_edges) if abs(int(g.ia[k]) - int(g.ib[k])) == 1]
+    gc = pgo.Graph.from_arrays(np.array(g.poses), np.array(g.ia)[keep], np.array(g.ib)[keep], np.array(g.meas)[keep], np.array(g.kind)[keep])
+    s = pgo.Solver(gc, pgo.Options(method=0, max_iters=3, linear_solver=2))
+    assert s.info().direct_rank == 0
+    summ = s.solve()
+    assert summ.final_cost <= summ.initial_cost and s.iter_records()[1]["pcg_rel_residual"] < 1e-9
     s.close()
 
 
@@ -254,7 +340,7 @@ def test_product_kernels_agree(pgo, oracle, monkeypatch):
     out = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("PGO_FUSED_P", fused)
-        s = pgo.Solver(gi, pgo.Options(method=1, max_iters=6))
+        s = pgo.Solver(gi, pgo.Options(method=1, max_iters=6, linear_solver=1))
         sm = s.solve()
         out[fused] = (s.poses(), sm.total_pcg_iters, sm.final_cost)
         s.close()
@@ -530,7 +616,7 @@ def test_graph_replay_is_bitwise_identical_to_eager(pgo):
     g = load(pgo, "INTEL", 50)
     out = []
     for flag in (1, 0):
-        s = pgo.Solver(g, pgo.Options(method=1, max_iters=5, use_graphs=flag, pcg_check_every=37))
+        s = pgo.Solver(g, pgo.Options(method=1, max_iters=5, use_graphs=flag, pcg_check_every=37, linear_solver=1))
         summ = s.solve()
         out.append((summ.final_cost, summ.total_pcg_iters, s.poses()))
         s.close()
@@ -869,7 +955,7 @@ def test_batch_handle_equals_individual_solves(pgo):
     import time
     graphs = _layer_problems(pgo, 64)
     opt = dict(method=0, max_iters=2, fixed_pose=0)
-    single = [pgo.Solver(g, pgo.Options(**opt)) for g in graphs]
+    single = [pgo.Solver(g, pgo.Options(linear_solver=1, **opt)) for g in graphs]   # like for like: the batch solves by PCG
     pgo.solve_batch(single[:2], 2)                                    # warm-up of the code path
     for s, g in zip(single[:2], graphs[:2]):
         s.set_poses(np.array(g.poses))

@@ -79,7 +79,7 @@ def test_sharded_inexact_solve_synthetic(tmp_path, world, halo, chain):
 def test_rccl_backend_single_rank(tmp_path):
     """RCCL communicator with the collectives forced on at world == 1 (identities): exercises
     ncclCommInitRank / ncclAllReduce / in-place ncclAllGather exactly as the multi-GPU solve issues them."""
-    cfg = dict(graph="INTEL", outliers=50, options=dict(method=1, max_iters=3, pcg_rtol=1e-10, pcg_max_iters=30000))
+    cfg = dict(graph="INTEL", outliers=50, options=dict(method=1, max_iters=3, pcg_rtol=1e-10, pcg_max_iters=30000, linear_solver=1))
     ref, ref_poses = run(1, cfg, tmp_path)
     res, poses = run(1, dict(cfg, comm="rccl"), tmp_path, env={"PGO_FORCE_COLLECTIVES": "1"}, tag="rccl")
     assert res[0]["summary"]["iterations"] == 3

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libpgo.so")
 SOURCES = ["host_graph.cpp", "structure.cpp", "comm.cpp", "solver.hip"]
-HEADERS = ["pgo_internal.h", "comm.h", "kernels.hip.h", "solo.hip.h", os.path.join(ROOT, "include", "pgo.h")]
+HEADERS = ["pgo_internal.h", "comm.h", "kernels.hip.h", "solo.hip.h", "direct.hip.h", os.path.join(ROOT, "include", "pgo.h")]
 
 
 def _hipcc() -> str:

@@ -1,0 +1,749 @@
+// Direct solve of the LM system (H + D'D) y = g for small chain-like graphs (the reference's own datasets: INTEL, MIT,
+// CSAIL, FR079 -- BASELINE configs[0]-[2]), standing in for the reference's SPARSE_NORMAL_CHOLESKY (main.cpp:154-163)
+// where block-Jacobi PCG needs hundreds of latency-bound iterations per LM iteration.
+//
+// With S the Jacobi column scaling, split the edges into the odometry CHAIN (one edge per consecutive pose pair) and
+// the rest (loop closures, bogus loops, extra short-range edges: m of them):
+//     H + D'D  =  T + V'V,     T = sum over chain edges (J_e S)'(J_e S) + D'D   (block tridiagonal, SPD, anchored by the
+//                                                                               constant pose),
+//                              V = the 3m x 3N matrix of the scaled Jacobian rows of the other edges.
+// Woodbury:  y = t - Z w,  t = T^-1 g,  Z = T^-1 V',  (I + V Z) w = V t.   Steps, all in fp64 and in a fixed order:
+//     k_dlr_setup    per pose the blocks M_i, C_i of T; per low-rank edge its two scaled 3x3 Jacobian blocks
+//     k_dlr_factor   block LDL' of T:  W_i = C_i S_{i-1}^-1,  S_i = M_i - W_i C_i'   (one wavefront, records through LDS)
+//     k_dlr_cols     Z and t: one lane per right-hand side sweeps the chain forward and backward (3m + 1 columns)
+//     k_dlr_cap      capacitance matrix I + V Z (dense, order 3m) and the right-hand side V t
+//     k_chol_panel   left-looking blocked Cholesky of it (32 x 32 blocks, one launch per block column)
+//     k_chol_solve   the two triangular solves (one workgroup)
+//     k_dlr_combine  y = t - Z w
+// followed by steps of iterative refinement against the assembled block-CSR matrix (k_spmv), which bring the solution to
+// the accuracy of a backward-stable direct solve (the capacitance matrix reaches condition 1e7 at large trust-region
+// radii).  Restated in numpy and checked against the oracle's SuperLU solve: tests/test_direct_solve_math.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pgo {
+namespace dev {
+
+constexpr int DLR_REC = 16;  // doubles per pose: input record M (6: 00 01 02 11 12 22) | C (9, row-major) | pad;
+                             // factor record W (9, row-major) | S^-1 (6) | pad
+constexpr int DLR_V = 18;    // doubles per low-rank edge: Xa (9) | Xb (9), X[k][c] = d e_k / d (pose)_c * scale_c
+constexpr int CHOL_NB = 32;
+
+struct DlrArgs {
+  int32_t n;                  // poses
+  int32_t m;                  // low-rank edges
+  int32_t K;                  // 3 m
+  int32_t Kp;                 // K rounded up to a multiple of CHOL_NB (order of the padded capacitance matrix)
+  int32_t ld;                 // row stride of T / Z (>= K + 1, a multiple of 64)
+  const double* jr;           // edge records (REC doubles)
+  const double* scale;        // [n x 3]
+  const double* d2;           // [n x 3] LM diagonal
+  const int32_t* e_ia;
+  const int32_t* e_ib;
+  const int32_t* chain_edge;  // [n]: local edge joining (i, i + 1), -1 for the last pose
+  const int32_t* lr_edge;     // [m]
+  const int32_t* va;          // [m] endpoints of the low-rank edges
+  const int32_t* vb;
+  double* trec;               // [n][DLR_REC]
+  double* fac;                // [n][DLR_REC]
+  double* vrec;               // [m][DLR_V]
+  double* Z;                  // [3n][ld]
+  double* cap;                // [Kp][Kp]
+  double* dwork;              // [Kp / 32][32][32]: the diagonal blocks of the capacitance matrix, updated by k_chol_panel
+  double* cvec;               // [Kp]
+};
+
+// scaled Jacobian blocks of edge e (record layout: kernels.hip.h REC; the second block is implied)
+__device__ __forceinline__ void dlr_blocks(const double* __restrict__ jr, int64_t e, const double* __restrict__ sa,
+                                           const double* __restrict__ sb, double (&Xa)[9], double (&Xb)[9]) {
+  const double* R = jr + e * REC;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double a0 = R[3 * k], a1 = R[3 * k + 1], a2 = R[3 * k + 2];
+    const double b2 = (k == 2) ? R[9] : 0.0;
+    Xa[3 * k] = a0 * sa[0];
+    Xa[3 * k + 1] = a1 * sa[1];
+    Xa[3 * k + 2] = a2 * sa[2];
+    Xb[3 * k] = -a0 * sb[0];
+    Xb[3 * k + 1] = -a1 * sb[1];
+    Xb[3 * k + 2] = b2 * sb[2];
+  }
+}
+
+__global__ void k_dlr_setup(DlrArgs A) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < A.n) {
+    const int i = idx;
+    double M[6] = {A.d2[3 * (int64_t)i], 0.0, 0.0, A.d2[3 * (int64_t)i + 1], 0.0, A.d2[3 * (int64_t)i + 2]};
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {  // 0: the edge (i - 1, i), 1: the edge (i, i + 1)
+      const int e = which == 0 ? (i > 0 ? A.chain_edge[i - 1] : -1) : A.chain_edge[i];
+      if (e < 0) continue;
+      const int a = A.e_ia[e], b = A.e_ib[e];
+      double Xa[9], Xb[9];
+      dlr_blocks(A.jr, e, A.scale + 3 * (int64_t)a, A.scale + 3 * (int64_t)b, Xa, Xb);
+      const bool self_is_a = (a == i);
+      double Xi[9], Xo[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        Xi[k] = self_is_a ? Xa[k] : Xb[k];
+        Xo[k] = self_is_a ? Xb[k] : Xa[k];
+      }
+      M[0] += Xi[0] * Xi[0] + Xi[3] * Xi[3] + Xi[6] * Xi[6];
+      M[1] += Xi[0] * Xi[1] + Xi[3] * Xi[4] + Xi[6] * Xi[7];
+      M[2] += Xi[0] * Xi[2] + Xi[3] * Xi[5] + Xi[6] * Xi[8];
+      M[3] += Xi[1] * Xi[1] + Xi[4] * Xi[4] + Xi[7] * Xi[7];
+      M[4] += Xi[1] * Xi[2] + Xi[4] * Xi[5] + Xi[7] * Xi[8];
+      M[5] += Xi[2] * Xi[2] + Xi[5] * Xi[5] + Xi[8] * Xi[8];
+      if (which == 0) {  // C_i = H_{i,i-1} = (J_i)'(J_{i-1})
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) C[3 * r + c] = Xi[r] * Xo[c] + Xi[3 + r] * Xo[3 + c] + Xi[6 + r] * Xo[6 + c];
+      }
+    }
+    double* o = A.trec + (int64_t)i * DLR_REC;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = M[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[6 + k] = C[k];
+    o[15] = 0.0;
+  } else if (idx < A.n + A.m) {
+    const int j = idx - A.n;
+    const int e = A.lr_edge[j];
+    const int a = A.e_ia[e], b = A.e_ib[e];
+    double Xa[9], Xb[9];
+    dlr_blocks(A.jr, e, A.scale + 3 * (int64_t)a, A.scale + 3 * (int64_t)b, Xa, Xb);
+    double* o = A.vrec + (int64_t)j * DLR_V;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      o[k] = Xa[k];
+      o[9 + k] = Xb[k];
+    }
+  }
+}
+
+// Block LDL' of the block-tridiagonal T, one wavefront (every lane runs the same recurrence; lane 0 stores).  The input
+// records pass through LDS in chunks of 128 poses, the next chunk is fetched while the current one is factorised: the
+// 3x3 recurrence itself (a cofactor inverse and two 3x3 products per pose, ~0.1 us) is the critical path.
+__global__ __launch_bounds__(64) void k_dlr_factor(const double* __restrict__ trec, int n, double* __restrict__ fac) {
+  constexpr int CH = 128;
+  __shared__ double buf[2][CH * DLR_REC];
+  const int lane = threadIdx.x;
+  const int n_chunks = (n + CH - 1) / CH;
+  const int64_t total = (int64_t)n * DLR_REC;
+  for (int k = 0; k < CH * DLR_REC / 64; ++k) {
+    const int64_t idx = (int64_t)k * 64 + lane;
+    buf[0][k * 64 + lane] = idx < total ? trec[idx] : 0.0;
+  }
+  __syncthreads();
+  double si0 = 0, si1 = 0, si2 = 0, si3 = 0, si4 = 0, si5 = 0;  // S_{i-1}^-1 (00 01 02 11 12 22)
+  for (int c = 0; c < n_chunks; ++c) {
+    double pre[CH * DLR_REC / 64];
+    if (c + 1 < n_chunks) {
+#pragma unroll
+      for (int k = 0; k < CH * DLR_REC / 64; ++k) {
+        const int64_t idx = (int64_t)(c + 1) * CH * DLR_REC + (int64_t)k * 64 + lane;
+        pre[k] = idx < total ? trec[idx] : 0.0;
+      }
+    }
+    const double* B = buf[c & 1];
+    const int cnt = min(CH, n - c * CH);
+    for (int ii = 0; ii < cnt; ++ii) {
+      const double* R = B + ii * DLR_REC;
+      const double m0 = R[0], m1 = R[1], m2 = R[2], m3 = R[3], m4 = R[4], m5 = R[5];
+      const double c0 = R[6], c1 = R[7], c2 = R[8], c3 = R[9], c4 = R[10], c5 = R[11], c6 = R[12], c7 = R[13], c8 = R[14];
+      // W = C S_{i-1}^-1   (S^-1 symmetric); zero for the first pose (si = 0, C = 0)
+      const double w0 = c0 * si0 + c1 * si1 + c2 * si2, w1 = c0 * si1 + c1 * si3 + c2 * si4, w2 = c0 * si2 + c1 * si4 + c2 * si5;
+      const double w3 = c3 * si0 + c4 * si1 + c5 * si2, w4 = c3 * si1 + c4 * si3 + c5 * si4, w5 = c3 * si2 + c4 * si4 + c5 * si5;
+      const double w6 = c6 * si0 + c7 * si1 + c8 * si2, w7 = c6 * si1 + c7 * si3 + c8 * si4, w8 = c6 * si2 + c7 * si4 + c8 * si5;
+      // S = M - W C'
+      const double a00 = m0 - (w0 * c0 + w1 * c1 + w2 * c2), a01 = m1 - (w0 * c3 + w1 * c4 + w2 * c5);
+      const double a02 = m2 - (w0 * c6 + w1 * c7 + w2 * c8), a11 = m3 - (w3 * c3 + w4 * c4 + w5 * c5);
+      const double a12 = m4 - (w3 * c6 + w4 * c7 + w5 * c8), a22 = m5 - (w6 * c6 + w7 * c7 + w8 * c8);
+      const double k00 = a11 * a22 - a12 * a12, k01 = a12 * a02 - a01 * a22, k02 = a01 * a12 - a11 * a02;
+      const double id = 1.0 / (a00 * k00 + a01 * k01 + a02 * k02);
+      si0 = k00 * id;
+      si1 = k01 * id;
+      si2 = k02 * id;
+      si3 = (a00 * a22 - a02 * a02) * id;
+      si4 = (a01 * a02 - a00 * a12) * id;
+      si5 = (a00 * a11 - a01 * a01) * id;
+      if (lane == 0) {
+        double2* o = reinterpret_cast<double2*>(fac + (int64_t)(c * CH + ii) * DLR_REC);
+        o[0] = make_double2(w0, w1);
+        o[1] = make_double2(w2, w3);
+        o[2] = make_double2(w4, w5);
+        o[3] = make_double2(w6, w7);
+        o[4] = make_double2(w8, si0);
+        o[5] = make_double2(si1, si2);
+        o[6] = make_double2(si3, si4);
+        o[7] = make_double2(si5, 0.0);
+      }
+    }
+    if (c + 1 < n_chunks) {
+      double* Bn = buf[(c + 1) & 1];
+#pragma unroll
+      for (int k = 0; k < CH * DLR_REC / 64; ++k) Bn[k * 64 + lane] = pre[k];
+    }
+    __syncthreads();
+  }
+}
+
+// T x = rhs for many right-hand sides at once.  A column's two sweeps over the chain are 2n dependent steps; they are cut
+// into `nseg` segments of `seglen` poses that run side by side: every (segment, column) pair sweeps its segment from a
+// zero state, and because the recurrences are affine in the incoming state,
+//     t_i = t_i(local) + G_i t_in,     G_i  = (-W_i) G_{i-1}         (G  = I before the segment's first pose),
+//     x_i = x_i(local) + Gb_i x_in,    Gb_i = (-W_{i+1}') Gb_{i+1}   (Gb = I after the segment's last pose),
+// the true values follow from the segment-end states by a short serial recursion over the segments (<= 31 steps of one
+// 3x3 product) and one independent update per pose.  G / Gb depend on the factorisation only (k_dlr_prefix).
+//     k_dlr_fwd   local forward sweep                       -> X (t local), E  (t at the segment ends)
+//     k_dlr_mid   incoming t, local backward sweep          -> X (x local), E2 (x at the segment starts)
+//     k_dlr_fix   incoming x, x_i += Gb_i x_in
+// Column c < K is row c of V (non-zero on the two endpoint poses of its edge); column `vec_col` is the dense vector
+// rhs_b - rhs_sub (rhs_sub may be null).  One lane per column, a workgroup = 256 columns of one segment.
+constexpr int DLR_PRE = 18;   // doubles per pose of the prefix products: G (9) | Gb (9), row-major
+constexpr int DLR_MAX_SEG = 32;
+struct DlrColsArgs {
+  const double* fac;
+  const double* pre;
+  int32_t n, ncols, K, vec_col, ld, nseg, seglen;
+  const double* vrec;
+  const int32_t* va;
+  const int32_t* vb;
+  const double* rhs_b;
+  const double* rhs_sub;
+  double* X;   // [3n][ld]
+  double* E;   // [nseg][3][ld]
+  double* E2;  // [nseg][3][ld]
+};
+
+// prefix products of one segment per thread: threads 0 .. nseg-1 forward (G), 32 .. 32+nseg-1 backward (Gb)
+__global__ __launch_bounds__(64) void k_dlr_prefix(const double* __restrict__ fac, int n, int nseg, int seglen, double* __restrict__ pre) {
+  const int t = threadIdx.x;
+  const bool back = t >= 32;
+  const int s = back ? t - 32 : t;
+  if (s >= nseg) return;
+  const int i0 = s * seglen, i1 = min(n, i0 + seglen);
+  double g[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (!back) {
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
+      const double* W = fac + (int64_t)i * DLR_REC;
+      double h[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) h[3 * r + c] = -(W[3 * r] * g[c] + W[3 * r + 1] * g[3 + c] + W[3 * r + 2] * g[6 + c]);
+      double* o = pre + (int64_t)i * DLR_PRE;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        g[k] = h[k];
+        o[k] = h[k];
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (int i = i1 - 1; i >= i0; --i) {
+      const double* W = fac + (int64_t)(i + 1) * DLR_REC;  // record n is all zero
+      double h[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) h[3 * r + c] = -(W[r] * g[c] + W[3 + r] * g[3 + c] + W[6 + r] * g[6 + c]);
+      double* o = pre + (int64_t)i * DLR_PRE + 9;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        g[k] = h[k];
+        o[k] = h[k];
+      }
+    }
+  }
+}
+
+struct DlrCol {   // what a lane knows about its column
+  int a, b;
+  double ra0, ra1, ra2, rb0, rb1, rb2;
+  bool act, isvec;
+};
+__device__ __forceinline__ DlrCol dlr_col(const DlrColsArgs& A, int col) {
+  DlrCol c;
+  c.act = col < A.ncols;
+  c.isvec = c.act && col == A.vec_col;
+  c.a = c.b = -1;
+  c.ra0 = c.ra1 = c.ra2 = c.rb0 = c.rb1 = c.rb2 = 0.0;
+  if (c.act && !c.isvec && col < A.K) {
+    const int j = col / 3, k = col - 3 * j;
+    c.a = A.va[j];
+    c.b = A.vb[j];
+    const double* v = A.vrec + (int64_t)j * DLR_V + 3 * k;
+    c.ra0 = v[0]; c.ra1 = v[1]; c.ra2 = v[2];
+    c.rb0 = v[9]; c.rb1 = v[10]; c.rb2 = v[11];
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(256) void k_dlr_fwd(DlrColsArgs A) {
+  constexpr int CH = 64;
+  __shared__ double fb[CH * DLR_REC];
+  const int tid = threadIdx.x;
+  const int col = blockIdx.x * 256 + tid;
+  const int s = blockIdx.y;
+  const int i0 = s * A.seglen, i1 = min(A.n, i0 + A.seglen);
+  const DlrCol c = dlr_col(A, col);
+  const int64_t ld = A.ld;
+  double* __restrict__ X = A.X + col;
+  double t0 = 0, t1 = 0, t2 = 0;
+  for (int c0 = i0; c0 < i1; c0 += CH) {
+    const int cnt = min(CH, i1 - c0);
+    __syncthreads();
+    for (int idx = tid; idx < cnt * DLR_REC; idx += 256) fb[idx] = A.fac[(int64_t)c0 * DLR_REC + idx];
+    __syncthreads();
+#pragma unroll 4
+    for (int ii = 0; ii < cnt; ++ii) {
+      const int i = c0 + ii;
+      double r0 = 0, r1 = 0, r2 = 0;
+      if (i == c.a) { r0 = c.ra0; r1 = c.ra1; r2 = c.ra2; }
+      if (i == c.b) { r0 += c.rb0; r1 += c.rb1; r2 += c.rb2; }
+      if (c.isvec) {
+        r0 = A.rhs_b[3 * (int64_t)i]; r1 = A.rhs_b[3 * (int64_t)i + 1]; r2 = A.rhs_b[3 * (int64_t)i + 2];
+        if (A.rhs_sub) { r0 -= A.rhs_sub[3 * (int64_t)i]; r1 -= A.rhs_sub[3 * (int64_t)i + 1]; r2 -= A.rhs_sub[3 * (int64_t)i + 2]; }
+      }
+      const double* W = fb + ii * DLR_REC;
+      const double n0 = r0 - (W[0] * t0 + W[1] * t1 + W[2] * t2);
+      const double n1 = r1 - (W[3] * t0 + W[4] * t1 + W[5] * t2);
+      const double n2 = r2 - (W[6] * t0 + W[7] * t1 + W[8] * t2);
+      t0 = n0; t1 = n1; t2 = n2;
+      if (c.act) {
+        X[(3 * (int64_t)i) * ld] = t0;
+        X[(3 * (int64_t)i + 1) * ld] = t1;
+        X[(3 * (int64_t)i + 2) * ld] = t2;
+      }
+    }
+  }
+  if (c.act) {
+    double* e = A.E + (int64_t)s * 3 * ld + col;
+    e[0] = t0; e[ld] = t1; e[2 * ld] = t2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dlr_mid(DlrColsArgs A) {
+  constexpr int CH = 64;
+  __shared__ double fb[(CH + 1) * DLR_REC];
+  __shared__ double gb[CH * 9];
+  const int tid = threadIdx.x;
+  const int col = blockIdx.x * 256 + tid;
+  const int s = blockIdx.y;
+  const int n = A.n;
+  const int i0 = s * A.seglen, i1 = min(n, i0 + A.seglen);
+  const bool act = col < A.ncols;
+  const int64_t ld = A.ld;
+  double* __restrict__ X = A.X + col;
+  // t entering this segment: t_in(q + 1) = E(q) + F_q t_in(q),  F_q = G at the last pose of segment q
+  double ti0 = 0, ti1 = 0, ti2 = 0;
+  for (int q = 0; q < s; ++q) {
+    const double* F = A.pre + (int64_t)(min(n, (q + 1) * A.seglen) - 1) * DLR_PRE;
+    double e0 = 0, e1 = 0, e2 = 0;
+    if (act) {
+      const double* e = A.E + (int64_t)q * 3 * ld + col;
+      e0 = e[0]; e1 = e[ld]; e2 = e[2 * ld];
+    }
+    const double n0 = e0 + F[0] * ti0 + F[1] * ti1 + F[2] * ti2;
+    const double n1 = e1 + F[3] * ti0 + F[4] * ti1 + F[5] * ti2;
+    const double n2 = e2 + F[6] * ti0 + F[7] * ti1 + F[8] * ti2;
+    ti0 = n0; ti1 = n1; ti2 = n2;
+  }
+  double z0 = 0, z1 = 0, z2 = 0;
+  const int n_chunks = (i1 - i0 + CH - 1) / CH;
+  for (int cc = n_chunks - 1; cc >= 0; --cc) {
+    const int c0 = i0 + cc * CH;
+    const int cnt = min(CH, i1 - c0);
+    __syncthreads();
+    for (int idx = tid; idx < (cnt + 1) * DLR_REC; idx += 256) fb[idx] = A.fac[(int64_t)c0 * DLR_REC + idx];  // fac has n + 1 records
+    for (int idx = tid; idx < cnt * 9; idx += 256) {
+      const int ii = idx / 9;
+      gb[idx] = A.pre[(int64_t)(c0 + ii) * DLR_PRE + (idx - 9 * ii)];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int ii = cnt - 1; ii >= 0; --ii) {
+      const int i = c0 + ii;
+      double u0 = 0, u1 = 0, u2 = 0;
+      if (act) {
+        u0 = X[(3 * (int64_t)i) * ld];
+        u1 = X[(3 * (int64_t)i + 1) * ld];
+        u2 = X[(3 * (int64_t)i + 2) * ld];
+      }
+      const double* G = gb + ii * 9;
+      u0 += G[0] * ti0 + G[1] * ti1 + G[2] * ti2;
+      u1 += G[3] * ti0 + G[4] * ti1 + G[5] * ti2;
+      u2 += G[6] * ti0 + G[7] * ti1 + G[8] * ti2;
+      const double* F = fb + ii * DLR_REC;
+      const double* Wn = fb + (ii + 1) * DLR_REC;
+      const double n0 = F[9] * u0 + F[10] * u1 + F[11] * u2 - (Wn[0] * z0 + Wn[3] * z1 + Wn[6] * z2);
+      const double n1 = F[10] * u0 + F[12] * u1 + F[13] * u2 - (Wn[1] * z0 + Wn[4] * z1 + Wn[7] * z2);
+      const double n2 = F[11] * u0 + F[13] * u1 + F[14] * u2 - (Wn[2] * z0 + Wn[5] * z1 + Wn[8] * z2);
+      z0 = n0; z1 = n1; z2 = n2;
+      if (act) {
+        X[(3 * (int64_t)i) * ld] = z0;
+        X[(3 * (int64_t)i + 1) * ld] = z1;
+        X[(3 * (int64_t)i + 2) * ld] = z2;
+      }
+    }
+  }
+  if (act) {
+    double* e = A.E2 + (int64_t)s * 3 * ld + col;
+    e[0] = z0; e[ld] = z1; e[2 * ld] = z2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dlr_fix(DlrColsArgs A) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (s == A.nseg - 1 || col >= A.ncols) return;  // nothing enters the last segment
+  const int n = A.n;
+  const int i0 = s * A.seglen, i1 = min(n, i0 + A.seglen);
+  const int64_t ld = A.ld;
+  double* __restrict__ X = A.X + col;
+  // x entering this segment from the right: x_in(q - 1) = E2(q) + Fb_q x_in(q),  Fb_q = Gb at the first pose of segment q
+  double x0 = 0, x1 = 0, x2 = 0;
+  for (int q = A.nseg - 1; q > s; --q) {
+    const double* F = A.pre + (int64_t)(q * A.seglen) * DLR_PRE + 9;
+    const double* e = A.E2 + (int64_t)q * 3 * ld + col;
+    const double n0 = e[0] + F[0] * x0 + F[1] * x1 + F[2] * x2;
+    const double n1 = e[ld] + F[3] * x0 + F[4] * x1 + F[5] * x2;
+    const double n2 = e[2 * ld] + F[6] * x0 + F[7] * x1 + F[8] * x2;
+    x0 = n0; x1 = n1; x2 = n2;
+  }
+#pragma unroll 4
+  for (int i = i0; i < i1; ++i) {
+    const double* G = A.pre + (int64_t)i * DLR_PRE + 9;
+    X[(3 * (int64_t)i) * ld] += G[0] * x0 + G[1] * x1 + G[2] * x2;
+    X[(3 * (int64_t)i + 1) * ld] += G[3] * x0 + G[4] * x1 + G[5] * x2;
+    X[(3 * (int64_t)i + 2) * ld] += G[6] * x0 + G[7] * x1 + G[8] * x2;
+  }
+}
+
+// capacitance matrix I + V Z (row p = row of V, column q = column of Z), its diagonal blocks once more in `dwork`, and
+// the right-hand side V t (t = column K of Z); padding rows / columns K .. Kp-1 = identity.
+// grid (ld / 256 rounded up, Kp), block 256.
+__global__ __launch_bounds__(256) void k_dlr_cap(DlrArgs A) {
+  const int p = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q > A.K && q >= A.Kp) return;
+  double val = 0.0;
+  if (p < A.K && q <= A.K) {
+    const int j = p / 3, k = p - 3 * j;
+    const int a = A.va[j], b = A.vb[j];
+    const double* v = A.vrec + (int64_t)j * DLR_V + 3 * k;
+    const double* za = A.Z + (3 * (int64_t)a) * A.ld + q;
+    const double* zb = A.Z + (3 * (int64_t)b) * A.ld + q;
+    val = v[0] * za[0] + v[1] * za[A.ld] + v[2] * za[2 * (int64_t)A.ld] + v[9] * zb[0] + v[10] * zb[A.ld] + v[11] * zb[2 * (int64_t)A.ld];
+  }
+  if (q == A.K) A.cvec[p] = val;  // the right-hand side V t (0 on the padding rows)
+  if (q < A.Kp) {                 // matrix column q; rows / columns K .. Kp-1 are identity padding
+    const double m = ((p < A.K && q < A.K) ? val : 0.0) + (p == q ? 1.0 : 0.0);
+    A.cap[(int64_t)p * A.Kp + q] = m;
+    if ((p >> 5) == (q >> 5)) A.dwork[(int64_t)(p >> 5) * 1024 + (p & 31) * 32 + (q & 31)] = m;
+  }
+}
+
+// Left-looking blocked Cholesky C = L L' of the capacitance matrix (32 x 32 blocks) together with the explicit inverse
+// N = L^-1 (the two triangular solves then are two dense, fully parallel products instead of 2 x nb dependent steps in
+// one workgroup: 200 us -> a few us per solve; the refinement against the assembled matrix absorbs the difference
+// between substitution and a product with the inverse).  One launch per block column kb; workgroups of 5 wavefronts:
+//   wavefront 4      factorises the diagonal block kb (its updates are complete: `dwork`) and inverts the factor, every
+//                    workgroup for itself -- nobody waits for another workgroup -- while
+//   wavefronts 0-3   accumulate the workgroup's block: the j are dealt to the four wavefronts, tiles pass through
+//                    wave-private LDS (next tiles requested before the current ones are multiplied), a 4 x 4 register tile
+//                    per lane, the four partial sums added in a fixed order;
+//   type 0 workgroups (block row i > kb of L):  P = C_ik - sum_{j<kb} L_ij L_kj',  L_ik = P L_kk^-T,  dwork_i -= L_ik L_ik'
+//   type 1 workgroups (block column k < kb of row kb of N):  N_kb,k = -L_kk^-1 sum_{j=k}^{kb-1} L_kb,j N_jk
+// Workgroup 0 stores L_kk^-1 = N_kk.
+constexpr int CHOL_T = 32 * 33;                                 // doubles of a padded 32 x 32 LDS tile
+constexpr int CHOL_LDS_DOUBLES = 2 * CHOL_T + 32 + 8 * CHOL_T + 64;  // Dm | Li | dinv | 4 waves x (A | B) tiles | column buffer
+constexpr size_t CHOL_LDS_BYTES = (size_t)CHOL_LDS_DOUBLES * sizeof(double);
+constexpr int CHOL_THREADS = 320;
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict__ Cm, double* __restrict__ Nm, double* __restrict__ dwork,
+                                                              int ld, int nb, int kb) {
+  extern __shared__ double sm[];
+  double* Dm = sm;                 // [32][33]
+  double* Li = sm + CHOL_T;        // [32][33]
+  double* dinv = sm + 2 * CHOL_T;  // [32]
+  double* tiles = sm + 2 * CHOL_T + 32;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63;
+  const int n_chol = nb - 1 - kb;
+  const bool type1 = (int)blockIdx.x >= n_chol;
+  const int i = kb + 1 + blockIdx.x;          // type 0: block row of L
+  const int kcol = (int)blockIdx.x - n_chol;  // type 1: block column of N
+  const bool has_work = type1 ? (kcol < kb) : (i < nb);
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  if (w == 4) {
+    // ---- diagonal block: L_kk (Dm) and its inverse (Li), one wavefront.  Lane r holds row r in registers; each step's
+    // column of L is handed to the other rows through LDS as ONE write + a batch of independent broadcast reads, so the
+    // 32-step dependency chain is sqrt, divide, one LDS round trip and one FMA per step (a form with every element
+    // in LDS took 60 us per launch, one with v_readlane broadcasts 40 us)
+    double* colb = sm + 2 * CHOL_T + 32 + 8 * CHOL_T;   // 64 doubles behind the tiles
+    for (int e = lane; e < 1024; e += 64) Dm[(e >> 5) * 33 + (e & 31)] = dwork[(int64_t)kb * 1024 + e];
+    wave_lds_sync();
+    const int row = lane & 31;
+    double a[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) a[c] = Dm[row * 33 + c];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      double* cb = colb + 32 * (k & 1);
+      if (lane == k) cb[k] = a[k];            // pivot
+      wave_lds_sync();
+      const double d = sqrt(cb[k]);
+      const double rs = 1.0 / d;
+      a[k] = (row == k) ? d : a[k] * rs;      // column k of L below the diagonal (rows above k: unused values)
+      if (lane < 32 && lane > k) cb[lane] = a[k];
+      wave_lds_sync();
+#pragma unroll
+      for (int c = k + 1; c < 32; ++c) a[c] -= a[k] * cb[c];
+    }
+    // L -> LDS (lower triangle, zeros above), reciprocal diagonal
+    if (lane < 32) {
+      double dsel = 0.0;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        Dm[row * 33 + c] = (c <= row) ? a[c] : 0.0;
+        dsel = (row == c) ? a[c] : dsel;
+      }
+      dinv[row] = 1.0 / dsel;
+    }
+    wave_lds_sync();
+    // column `row` of the inverse, in LDS: Li[r][c] = -(sum_{k=c}^{r-1} L[r][k] Li[k][c]) / L[r][r]; the L entries are
+    // broadcast reads, the lane's own earlier results come back from its LDS column (conflict-free: stride 1 over lanes)
+    if (lane < 32) {
+      for (int r = 0; r < 32; ++r) Li[r * 33 + row] = (r == row) ? dinv[r] : 0.0;
+      for (int r = 1; r < 32; ++r) {
+        double s0 = 0.0, s1 = 0.0;
+        int k = 0;
+        for (; k + 1 < r; k += 2) {
+          s0 += Dm[r * 33 + k] * Li[k * 33 + row];
+          s1 += Dm[r * 33 + k + 1] * Li[(k + 1) * 33 + row];
+        }
+        if (k < r) s0 += Dm[r * 33 + k] * Li[k * 33 + row];
+        if (r > row) Li[r * 33 + row] = -(s0 + s1) * dinv[r];   // (entries above the lane's diagonal stay 0, so k < row adds 0)
+      }
+    }
+  } else if (has_work) {
+    // ---- accumulation, j dealt to the four wavefronts
+    double* At = tiles + (size_t)w * 2 * CHOL_T;
+    double* Bt = At + CHOL_T;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int j_lo = type1 ? kcol : 0;
+    // rows of the A tile: block row i (type 0) or kb (type 1) of L; B tile: block (kb, j) of L, transposed use (type 0),
+    // or block (j, kcol) of N, plain use (type 1)
+    const double* Abase = Cm + (int64_t)(32 * (type1 ? kb : i)) * ld;
+    double2 ra[8], rb[8];
+    auto request = [&](int j) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int e = it * 128 + lane * 2;
+        const int r = e >> 5, k = e & 31;
+        ra[it] = *reinterpret_cast<const double2*>(Abase + (int64_t)r * ld + 32 * j + k);
+        rb[it] = type1 ? *reinterpret_cast<const double2*>(Nm + (int64_t)(32 * j + r) * ld + 32 * kcol + k)
+                       : *reinterpret_cast<const double2*>(Cm + (int64_t)(32 * kb + r) * ld + 32 * j + k);
+      }
+    };
+    int j = j_lo + w;
+    if (j < kb) request(j);
+    for (; j < kb; j += 4) {
+      wave_lds_sync();   // the previous tiles have been read
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int e = it * 128 + lane * 2;
+        const int r = e >> 5, k = e & 31;
+        At[k * 33 + r] = ra[it].x;          // At[t][r] = A[r][t]
+        At[(k + 1) * 33 + r] = ra[it].y;
+        if (type1) {                        // Bt[t][c] = N_jk[t][c]: the tile as it is
+          Bt[r * 33 + k] = rb[it].x;
+          Bt[r * 33 + k + 1] = rb[it].y;
+        } else {                            // Bt[t][c] = L_kj[c][t]
+          Bt[k * 33 + r] = rb[it].x;
+          Bt[(k + 1) * 33 + r] = rb[it].y;
+        }
+      }
+      wave_lds_sync();
+      if (j + 4 < kb) request(j + 4);
+#pragma unroll 4
+      for (int k = 0; k < 32; ++k) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = At[k * 33 + 4 * ly + u];
+          b[u] = Bt[k * 33 + 4 * lx + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+      }
+    }
+    wave_lds_sync();
+    // partial sums -> LDS (the wave's own A tile, now as [r][c])
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) At[(4 * ly + u) * 33 + 4 * lx + v] = acc[u][v];
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < 256) {
+    for (int e = tid; e < 1024; e += 256) {
+      const int r = e >> 5, c = e & 31;
+      Cm[(int64_t)(32 * kb + r) * ld + 32 * kb + c] = c <= r ? Dm[r * 33 + c] : 0.0;
+      Nm[(int64_t)(32 * kb + r) * ld + 32 * kb + c] = Li[r * 33 + c];
+    }
+  }
+  if (!has_work) return;
+  double* Ps = tiles + CHOL_T;   // wave 0's B tile: P, later the result
+  const int pr = (tid & 255) >> 3, pc = 4 * (tid & 7);
+  double pv[4] = {0.0, 0.0, 0.0, 0.0};
+  if (tid < 256) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int o = pr * 33 + pc + v;
+      const double sum = ((tiles[o] + tiles[2 * CHOL_T + o]) + tiles[4 * CHOL_T + o]) + tiles[6 * CHOL_T + o];
+      pv[v] = type1 ? sum : Cm[(int64_t)(32 * i + pr) * ld + 32 * kb + pc + v] - sum;
+    }
+  }
+  __syncthreads();
+  if (tid < 256) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Ps[pr * 33 + pc + v] = pv[v];
+  }
+  __syncthreads();
+  double xv[4] = {0.0, 0.0, 0.0, 0.0};
+  if (tid < 256) {
+    if (type1) {  // N_kb,k = -Linv P:  out[r][c] = -sum_t Li[r][t] P[t][c]
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) {
+        const double lk = Li[pr * 33 + k];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xv[v] -= lk * Ps[k * 33 + pc + v];
+      }
+    } else {      // L_ik = P Linv':  out[r][c] = sum_t P[r][t] Li[c][t]
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) {
+        const double pk = Ps[pr * 33 + k];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xv[v] += pk * Li[(pc + v) * 33 + k];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 256) {
+    double* out = type1 ? Nm + (int64_t)(32 * kb + pr) * ld + 32 * kcol + pc : Cm + (int64_t)(32 * i + pr) * ld + 32 * kb + pc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      out[v] = xv[v];
+      Ps[pr * 33 + pc + v] = xv[v];
+    }
+  }
+  if (type1) return;
+  __syncthreads();
+  if (tid < 256) {  // dwork_i -= L_ik L_ik'
+    double dv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double xk = Ps[pr * 33 + k];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dv[v] += xk * Ps[(pc + v) * 33 + k];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dwork[(int64_t)i * 1024 + pr * 32 + pc + v] -= dv[v];
+  }
+}
+
+// y = N x (trans = 0: one workgroup per block row) or y = N' x (trans = 1: one workgroup per block column), N lower
+// block-triangular with full 32 x 32 blocks (zeros above the diagonal inside the diagonal blocks)
+__global__ __launch_bounds__(256) void k_tri_apply(const double* __restrict__ Nm, int ld, int nb, const double* __restrict__ x,
+                                                    double* __restrict__ y, int trans) {
+  __shared__ double red[8][32];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  if (!trans) {
+    const int r = tid >> 3, p = tid & 7;
+    const double* row = Nm + (int64_t)(32 * b + r) * ld;
+    double s = 0.0;
+#pragma unroll 8
+    for (int c = p; c < 32 * (b + 1); c += 8) s += row[c] * x[c];
+    s += __shfl_xor(s, 1, 8);
+    s += __shfl_xor(s, 2, 8);
+    s += __shfl_xor(s, 4, 8);
+    if (p == 0) y[32 * b + r] = s;
+  } else {
+    const int c = tid & 31, p = tid >> 5;
+    double s = 0.0;
+#pragma unroll 8
+    for (int r = 32 * b + p; r < 32 * nb; r += 8) s += Nm[(int64_t)r * ld + 32 * b + c] * x[r];
+    red[p][c] = s;
+    __syncthreads();
+    if (p == 0) {
+      double t = red[0][c];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) t += red[q][c];
+      y[32 * b + c] = t;
+    }
+  }
+}
+
+// w[p] = (row p of V) . x  for a single vector x given as column `xcol` of X ([3n][xld]); rows K .. Kp-1 = 0
+__global__ void k_dlr_vdot(DlrArgs A, const double* __restrict__ X, int xld, int xcol, double* __restrict__ w) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= A.Kp) return;
+  double val = 0.0;
+  if (p < A.K) {
+    const int j = p / 3, k = p - 3 * j;
+    const int a = A.va[j], b = A.vb[j];
+    const double* v = A.vrec + (int64_t)j * DLR_V + 3 * k;
+    const double* xa = X + (3 * (int64_t)a) * xld + xcol;
+    const double* xb = X + (3 * (int64_t)b) * xld + xcol;
+    val = v[0] * xa[0] + v[1] * xa[xld] + v[2] * xa[2 * (int64_t)xld] + v[9] * xb[0] + v[10] * xb[xld] + v[11] * xb[2 * (int64_t)xld];
+  }
+  w[p] = val;
+}
+
+// y[row] (+)= t[row] - sum_q Z[row][q] w[q]; one wavefront per row, t = column tcol of Tm ([rows][tld])
+__global__ __launch_bounds__(256) void k_dlr_combine(const double* __restrict__ Z, int ld, int K, const double* __restrict__ w,
+                                                      const double* __restrict__ Tm, int tld, int tcol, int nrows,
+                                                      double* __restrict__ y, int add) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  double s = 0.0;
+  const double* zr = Z + (int64_t)row * ld;
+  for (int q = lane; q < K; q += 64) s += zr[q] * w[q];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) {
+    const double v = Tm[(int64_t)row * tld + tcol] - s;
+    y[row] = add ? y[row] + v : v;
+  }
+}
+
+// r = b - Ap
+__global__ void k_dlr_resid(int64_t n, const double* __restrict__ b, const double* __restrict__ ap, double* __restrict__ r) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) r[i] = b[i] - ap[i];
+}
+
+}  // namespace dev
+}  // namespace pgo

@@ -28,6 +28,7 @@
 #include "comm.h"
 #include "kernels.hip.h"
 #include "solo.hip.h"
+#include "direct.hip.h"
 #include "pgo_internal.h"
 
 using pgo::fail;
@@ -169,6 +170,14 @@ struct pgo_handle {
   int solo_steps = 0, solo_scan = 0;
   // grids
   int g_edge = 1, g_rows = 1, g_vec = 1, g_flat = 1, g_spmv = 1, g_asm = 1;
+  // direct solve for small chain-like graphs (direct.hip.h): T (odometry chain) + V'V (the other edges) by Woodbury
+  bool direct = false;
+  int dl_m = 0, dl_K = 0, dl_Kp = 0, dl_ld = 0, dl_refine = 1;
+  int32_t *dl_chain_edge = nullptr, *dl_lr_edge = nullptr, *dl_va = nullptr, *dl_vb = nullptr;
+  double *dl_trec = nullptr, *dl_fac = nullptr, *dl_pre = nullptr, *dl_vrec = nullptr, *dl_Z = nullptr, *dl_cap = nullptr, *dl_dwork = nullptr,
+         *dl_nm = nullptr, *dl_cy = nullptr, *dl_cvec = nullptr, *dl_x1 = nullptr, *dl_E = nullptr, *dl_E2 = nullptr;
+  int dl_nseg = 1, dl_seglen = 1;
+  double dl_rel = 0.0;  // |g - (H + D'D) y| / |g| of the latest direct solve
 
   // LM state (TrustRegionMinimizer)
   bool lm_active = false, lin_valid = false, lm_done = false;
@@ -512,6 +521,8 @@ struct pgo_handle {
   int lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, double t0, int k_it, double rel);
   int prepare_system();
   int pcg(int* iters, double* rel);
+  int direct_setup(int32_t N);
+  int direct_solve();
   void fill_summary(pgo_summary* s) const;
 };
 
@@ -848,6 +859,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     PGOC(upload(fixed_mask, fixed_mask_h));
   }
   if (batch_mode) PGOC(dalloc(&edge_cost, std::max<int64_t>(EL, 1)));
+  PGOC(direct_setup(N));
   return sync();
 }
 
@@ -962,6 +974,186 @@ int pgo_handle::lm_begin() {
     printf("%4d % .6e  % .2e  % .2e  % .2e  % .2e  % .2e  %6d  %.1e\n", 0, cost, 0.0, gmax, 0.0, 0.0, radius, 0, 0.0);
   }
   return PGO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Direct solve for small chain-like graphs (direct.hip.h).  opt.linear_solver: 0 = auto, 1 = PCG, 2 = direct.
+// Auto picks it in the "exact" mode only (pcg_rtol <= 1e-8, where PCG stands in for the reference's
+// SPARSE_NORMAL_CHOLESKY, main.cpp:154-163) and only while the caller left the preconditioner to the library; it needs
+// one rank, METHOD 0 / 1, a constant pose, an edge between every pair of consecutive poses, and few enough other edges.
+namespace {
+constexpr int DIRECT_MAX_POSES = 16384;
+constexpr int DIRECT_MAX_RANK = 1024;   // 3 x (edges outside the chain) + 1: order of the dense capacitance matrix (k_chol_solve: <= 32 blocks)
+}  // namespace
+
+int pgo_handle::direct_setup(int32_t N) {
+  const int world = comm ? comm->world : 1;
+  int want = opt.linear_solver;
+  if (const char* de = getenv("PGO_DIRECT")) want = atoi(de) ? 2 : 1;  // experiments: force on / off
+  if (want == 1) return PGO_OK;
+  if (want != 0 && want != 2) return fail(PGO_ERR_INVALID_ARG, "linear_solver: 0 = auto, 1 = PCG, 2 = direct (chain + low rank)");
+  auto no = [&](const std::string& why) -> int {
+    if (want == 2) return fail(PGO_ERR_UNSUPPORTED, "linear_solver = direct: " + why);
+    return PGO_OK;
+  };
+  if (want == 0 && (!(opt.pcg_rtol <= 1e-8) || opt.pcg_chain_len != -1 || opt.pcg_block_poses != 0)) return PGO_OK;
+  if (world != 1 || force_collectives) return no("one rank only");
+  if (batch_mode) return no("not inside a batched handle");
+  if (has_sw || info_mode) return no("METHOD 0 / 1 without information weighting only");
+  if (fixed_internal < 0) return no("needs a constant pose (it anchors the chain)");
+  if (!perm.empty()) return no("the internal pose ordering is on");
+  if (N < 2 || N > DIRECT_MAX_POSES) return no("2 .. " + std::to_string(DIRECT_MAX_POSES) + " poses");
+  const int64_t EL = S.n_edges_local;
+  std::vector<int32_t> chain((size_t)N, -1), lr, va, vb;
+  for (int64_t e = 0; e < EL; ++e) {
+    const int32_t lo_p = std::min(S.ia[e], S.ib[e]), hi_p = std::max(S.ia[e], S.ib[e]);
+    if (hi_p == lo_p + 1 && chain[lo_p] < 0) {
+      chain[lo_p] = (int32_t)e;
+    } else {
+      lr.push_back((int32_t)e);
+      va.push_back(S.ia[e]);
+      vb.push_back(S.ib[e]);
+    }
+  }
+  for (int32_t i = 0; i + 1 < N; ++i)
+    if (chain[i] < 0) return no("poses " + std::to_string(i) + " and " + std::to_string(i + 1) + " are not joined by an edge");
+  dl_m = (int)lr.size();
+  dl_K = 3 * dl_m;
+  if (dl_K + 1 > DIRECT_MAX_RANK) return no(std::to_string(dl_m) + " edges outside the odometry chain (at most " + std::to_string((DIRECT_MAX_RANK - 1) / 3) + ")");
+  dl_Kp = std::max(dev::CHOL_NB, ((dl_K + dev::CHOL_NB - 1) / dev::CHOL_NB) * dev::CHOL_NB);
+  dl_ld = ((dl_K + 1 + 63) / 64) * 64;
+  if (const char* re = getenv("PGO_DIRECT_REFINE")) dl_refine = std::max(0, atoi(re));
+  PGOC(dalloc(&dl_chain_edge, N));
+  PGOC(dalloc(&dl_lr_edge, std::max(1, dl_m)));
+  PGOC(dalloc(&dl_va, std::max(1, dl_m)));
+  PGOC(dalloc(&dl_vb, std::max(1, dl_m)));
+  PGOC(upload(dl_chain_edge, chain));
+  PGOC(upload(dl_lr_edge, lr));
+  PGOC(upload(dl_va, va));
+  PGOC(upload(dl_vb, vb));
+  PGOC(dalloc(&dl_trec, (int64_t)dev::DLR_REC * N));
+  PGOC(dalloc(&dl_fac, (int64_t)dev::DLR_REC * (N + 1)));
+  PGOC(dalloc(&dl_vrec, (int64_t)dev::DLR_V * std::max(1, dl_m)));
+  PGOC(dalloc(&dl_Z, (int64_t)3 * N * dl_ld));
+  PGOC(dalloc(&dl_x1, (int64_t)3 * N * 64));
+  PGOC(dalloc(&dl_cap, (int64_t)dl_Kp * dl_Kp));
+  PGOC(dalloc(&dl_dwork, (int64_t)(dl_Kp / 32) * 1024));
+  PGOC(dalloc(&dl_nm, (int64_t)dl_Kp * dl_Kp));
+  PGOC(dalloc(&dl_cy, dl_Kp));
+  PGOC(dalloc(&dl_pre, (int64_t)dev::DLR_PRE * N));
+  dl_seglen = std::max(1, (N + dev::DLR_MAX_SEG - 1) / dev::DLR_MAX_SEG);
+  dl_nseg = (N + dl_seglen - 1) / dl_seglen;
+  PGOC(dalloc(&dl_E, (int64_t)dl_nseg * 3 * dl_ld));
+  PGOC(dalloc(&dl_E2, (int64_t)dl_nseg * 3 * dl_ld));
+  HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_chol_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::CHOL_LDS_BYTES));
+  PGOC(dalloc(&dl_cvec, dl_Kp));
+  PGOC(sync());  // the host lists die with this scope
+  direct = true;
+  return PGO_OK;
+}
+
+// (H + D'D) y = gs by Woodbury on chain + low rank, then iterative refinement against the assembled matrix; leaves the
+// true residual in r (the model-decrease identity of lm_iteration_tail reads it) and |r|^2, |gs|^2 in scal[8..9].
+int pgo_handle::direct_solve() {
+  const int n = S.n_loc, K = dl_K, Kp = dl_Kp, nb = dl_Kp / 32;
+  dev::DlrArgs A;
+  A.n = n;
+  A.m = dl_m;
+  A.K = K;
+  A.Kp = Kp;
+  A.ld = dl_ld;
+  A.jr = jr;
+  A.scale = scale;
+  A.d2 = d2;
+  A.e_ia = e_ia;
+  A.e_ib = e_ib;
+  A.chain_edge = dl_chain_edge;
+  A.lr_edge = dl_lr_edge;
+  A.va = dl_va;
+  A.vb = dl_vb;
+  A.trec = dl_trec;
+  A.fac = dl_fac;
+  A.vrec = dl_vrec;
+  A.Z = dl_Z;
+  A.cap = dl_cap;
+  A.dwork = dl_dwork;
+  A.cvec = dl_cvec;
+  hipLaunchKernelGGL(dev::k_dlr_setup, dim3((n + dl_m + 255) / 256), dim3(256), 0, stream, A);
+  PGOC(check_launch("k_dlr_setup"));
+  hipLaunchKernelGGL(dev::k_dlr_factor, dim3(1), dim3(64), 0, stream, (const double*)dl_trec, n, dl_fac);
+  PGOC(check_launch("k_dlr_factor"));
+  hipLaunchKernelGGL(dev::k_dlr_prefix, dim3(1), dim3(64), 0, stream, (const double*)dl_fac, n, dl_nseg, dl_seglen, dl_pre);
+  PGOC(check_launch("k_dlr_prefix"));
+  dev::DlrColsArgs C;
+  C.fac = dl_fac;
+  C.pre = dl_pre;
+  C.n = n;
+  C.ncols = K + 1;
+  C.K = K;
+  C.vec_col = K;
+  C.ld = dl_ld;
+  C.nseg = dl_nseg;
+  C.seglen = dl_seglen;
+  C.vrec = dl_vrec;
+  C.va = dl_va;
+  C.vb = dl_vb;
+  C.rhs_b = gs;
+  C.rhs_sub = nullptr;
+  C.X = dl_Z;
+  C.E = dl_E;
+  C.E2 = dl_E2;
+  auto solve_columns = [&](const dev::DlrColsArgs& Q) -> int {
+    const dim3 grid((Q.ncols + 255) / 256, Q.nseg);
+    hipLaunchKernelGGL(dev::k_dlr_fwd, grid, dim3(256), 0, stream, Q);
+    hipLaunchKernelGGL(dev::k_dlr_mid, grid, dim3(256), 0, stream, Q);
+    hipLaunchKernelGGL(dev::k_dlr_fix, grid, dim3(256), 0, stream, Q);
+    return check_launch("k_dlr_fwd / _mid / _fix");
+  };
+  PGOC(solve_columns(C));
+  hipLaunchKernelGGL(dev::k_dlr_cap, dim3((std::max(Kp, K + 1) + 255) / 256, Kp), dim3(256), 0, stream, A);
+  PGOC(check_launch("k_dlr_cap"));
+  for (int kb = 0; kb < nb; ++kb) {
+    hipLaunchKernelGGL(dev::k_chol_panel, dim3(std::max(1, nb - 1)), dim3(dev::CHOL_THREADS), dev::CHOL_LDS_BYTES, stream, dl_cap, dl_nm, dl_dwork, Kp, nb, kb);
+    PGOC(check_launch("k_chol_panel"));
+  }
+  auto capacitance_solve = [&]() -> int {  // cvec <- (L L')^-1 cvec = N' (N cvec)
+    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)dl_nm, Kp, nb, (const double*)dl_cvec, dl_cy, 0);
+    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)dl_nm, Kp, nb, (const double*)dl_cy, dl_cvec, 1);
+    return check_launch("k_tri_apply");
+  };
+  PGOC(capacitance_solve());
+  hipLaunchKernelGGL(dev::k_dlr_combine, dim3((3 * n + 3) / 4), dim3(256), 0, stream, (const double*)dl_Z, dl_ld, K, (const double*)dl_cvec,
+                     (const double*)dl_Z, dl_ld, K, 3 * n, y, 0);
+  PGOC(check_launch("k_dlr_combine"));
+  auto residual_product = [&]() -> int {  // ap = (H + D'D) y
+    hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
+    PGOC(check_launch("k_scatter_owned"));
+    return spmv_enqueue(p_full, ap, part[0], 1, nullptr);
+  };
+  for (int it = 0; it < dl_refine; ++it) {
+    PGOC(residual_product());
+    dev::DlrColsArgs C1 = C;
+    C1.ncols = 1;
+    C1.K = 0;
+    C1.vec_col = 0;
+    C1.ld = 64;
+    C1.rhs_sub = ap;
+    C1.X = dl_x1;
+    PGOC(solve_columns(C1));
+    hipLaunchKernelGGL(dev::k_dlr_vdot, dim3((Kp + 255) / 256), dim3(256), 0, stream, A, (const double*)dl_x1, 64, 0, dl_cvec);
+    PGOC(check_launch("k_dlr_vdot"));
+    PGOC(capacitance_solve());
+    hipLaunchKernelGGL(dev::k_dlr_combine, dim3((3 * n + 3) / 4), dim3(256), 0, stream, (const double*)dl_Z, dl_ld, K, (const double*)dl_cvec,
+                       (const double*)dl_x1, 64, 0, 3 * n, y, 1);
+    PGOC(check_launch("k_dlr_combine"));
+  }
+  PGOC(residual_product());
+  hipLaunchKernelGGL(dev::k_dlr_resid, dim3((3 * n + 255) / 256), dim3(256), 0, stream, (int64_t)3 * n, (const double*)gs, (const double*)ap, r);
+  PGOC(check_launch("k_dlr_resid"));
+  hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)r, (const double*)r, part[2]);
+  hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)gs, (const double*)gs, part[4]);
+  PGOC(check_launch("k_dot"));
+  return reduce_to_scal({{part[2], g_flat, 0}, {part[4], g_flat, 0}}, 8);
 }
 
 // block-Jacobi PCG on (H + D2) y = gs, y0 = 0.  Host checks the residual every
@@ -1177,7 +1369,8 @@ int pgo_handle::lm_iteration(bool* stop) {
   PGOC(prepare_system());
   int k_it = 0;
   double rel = 0.0;
-  PGOC(pcg(&k_it, &rel));
+  if (direct) PGOC(direct_solve());
+  else PGOC(pcg(&k_it, &rel));
   return lm_iteration_tail(stop, R, it0, t0, k_it, rel);
 }
 
@@ -1203,7 +1396,7 @@ int pgo_handle::prepare_system() {
     hipLaunchKernelGGL(dev::k_prepare_groups, dim3(grp_prep_grid), dim3(dev::WG), grp_lds, stream, GA);
     PGOC(check_launch("k_prepare_groups"));
   }
-  if (chain_len) {   // (the records are complete: C part from k_assemble, M part from k_prepare)
+  if (chain_len && !direct) {   // (the records are complete: C part from k_assemble, M part from k_prepare)
     const int n_seg = (S.n_loc + chain_len - 1) / chain_len;
     if ((chain_chunk ? chain_chunk : dev::CHAIN_CHUNK) == 2)
       hipLaunchKernelGGL(dev::k_chain_factor<2>, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
@@ -1250,8 +1443,9 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
     h_scal[2] = h_solo->step2;
   } else {
     PGOC(reduce_to_scal({{part[1], g_flat, 0}, {part[0], g_flat, 0}, {part[3], g_flat, 0}, {part[5], g_flat, 0}}, 0));
-    PGOC(fetch_scal(0, 4));
+    PGOC(fetch_scal(0, direct ? 10 : 4));
     h_scal[1] = h_scal[0] - h_scal[1] - h_scal[3];   // y.(H y)
+    if (direct) R.pcg_rel_residual = dl_rel = (h_scal[9] > 0.0) ? std::sqrt(h_scal[8] / h_scal[9]) : 0.0;
   }
   if (has_sw) {
     PGOC(fetch_scal(13, 2));
@@ -1422,6 +1616,7 @@ void pgo_options_default(pgo_options* o) {
   o->pcg_chain_len = -1;
   o->halo_exchange = 1;  // point-to-point exchange of the referenced rows; 0 = all-gather
   o->halo_overlap = 0;   // opt-in: the two-stream schedule has never run against a real peer (no multi-GPU lease yet)
+  o->linear_solver = 0;  // auto: the direct chain + low-rank solve on small chain-like graphs in the exact mode, else PCG
 }
 
 int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
@@ -1710,6 +1905,8 @@ int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   out->device_bytes = h->device_bytes;
   out->host_enqueue_us_per_pcg_iter = h->n_enqueued > 0 ? 1e6 * h->t_enqueue / (double)h->n_enqueued : 0.0;
   out->pcg_graph_replay = (h->cg_graph_exec != nullptr && !h->graph_failed) ? 1 : 0;
+  out->linear_solver = h->direct ? 2 : 1;
+  out->direct_rank = h->direct ? h->dl_K : 0;
   return PGO_OK;
 }
 
