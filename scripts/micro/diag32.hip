@@ -143,6 +143,43 @@ __device__ void diag_v4(double* Dm, double* Li, int lane) {
     }
   }
 }
+
+// variant 7: L D L' and the inverse of the unit triangle in ONE 32-step loop, rows of both in registers (lane r: row r of
+// A and row r of N), v_readlane broadcasts only: step k scales column k, updates the trailing row entries
+// a_rc -= Lt_rk (Lt_ck D_k) for c > k, and eliminates column k from the inverse N_r. -= Lt_rk N_k. (row k of N is final
+// by then); no LDS access and no sqrt / divide in the chain
+__device__ void diag_v7(double* Dm, double* Li, int lane) {
+  const int row = lane & 31;
+  double a[32], n[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    a[c] = Dm[row * 33 + c];
+    n[c] = (c == row) ? 1.0 : 0.0;
+  }
+  double dsel = 1.0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const double d = readlane_f64(a[k], k);
+    const double rd = fast_rcp(d);
+    dsel = (row == k) ? d : dsel;
+    const double ak = a[k];
+    const double l = (row > k) ? ak * rd : 0.0;   // Lt_rk (0 on and above the diagonal: those rows are finished)
+    a[k] = l;
+#pragma unroll
+    for (int c = k + 1; c < 32; ++c) a[c] -= l * readlane_f64(ak, c);
+#pragma unroll
+    for (int c = 0; c <= k; ++c) n[c] -= l * readlane_f64(n[c], k);
+  }
+  const double sd = sqrt(dsel), isd = 1.0 / sd;
+  if (lane < 32) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const double sc = readlane_f64(sd, c);
+      Dm[row * 33 + c] = (c < row) ? a[c] * sc : ((c == row) ? sd : 0.0);
+      Li[row * 33 + c] = n[c] * isd;
+    }
+  }
+}
 template <int V>
 __global__ __launch_bounds__(V == 2 ? 256 : 64) void k_diag(const double* in, double* outL, double* outI, int reps) {
   __shared__ double Dm[32 * 33], Li[32 * 33], dinv[32], colb[64];
@@ -175,6 +212,8 @@ __global__ __launch_bounds__(V == 2 ? 256 : 64) void k_diag(const double* in, do
       diag_v3(Dm, Li, lane);
     } else if (V == 4) {
       diag_v4<0>(Dm, Li, lane);
+    } else if (V == 7) {
+      diag_v7(Dm, Li, lane);
     } else if (V == 5) {
       diag_v4<1>(Dm, Li, lane);
     } else if (V == 6) {
@@ -242,7 +281,7 @@ int main() {
   hipMemcpy(dA, A.data(), 8192, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int reps = 200;
-  for (int v = 2; v < 7; ++v) {
+  for (int v = 4; v < 8; ++v) {
     for (int pass = 0; pass < 2; ++pass) {
       hipEventRecord(e0);
       if (v == 0) hipLaunchKernelGGL(k_diag<0>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
@@ -252,6 +291,7 @@ int main() {
       if (v == 4) hipLaunchKernelGGL(k_diag<4>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
       if (v == 5) hipLaunchKernelGGL(k_diag<5>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
       if (v == 6) hipLaunchKernelGGL(k_diag<6>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
+      if (v == 7) hipLaunchKernelGGL(k_diag<7>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
       hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -239,7 +239,8 @@ def test_options_defaults_are_ceres_defaults(pgo):
     assert (o.ftol, o.gtol, o.ptol) == (1e-6, 1e-10, 1e-8)
     assert (o.radius0, o.max_radius, o.min_radius) == (1e4, 1e16, 1e-32)
     assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-3, 1e-6, 1e32)
-    assert ctypes.sizeof(pgo.Options) == 4 * 4 + 12 * 8 + 4 * 4 + 8 * 4
+    assert ctypes.sizeof(pgo.Options) == 4 * 4 + 12 * 8 + 4 * 4 + 8 * 4 + 2 * 4
+    assert o.linear_solver == 0 and (o.pcg_rtol, o.pcg_chain_len, o.pcg_block_poses) == (1e-10, -1, 0)   # auto: the direct solve where it applies
     assert ctypes.sizeof(pgo.IterRecord) == 80 and ctypes.sizeof(pgo.Summary) == 72
 
 

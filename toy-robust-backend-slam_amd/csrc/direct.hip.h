@@ -367,29 +367,35 @@ __global__ __launch_bounds__(256) void k_dlr_mid(DlrColsArgs A) {
       gb[idx] = A.pre[(int64_t)(c0 + ii) * DLR_PRE + (idx - 9 * ii)];
     }
     __syncthreads();
-#pragma unroll 4
-    for (int ii = cnt - 1; ii >= 0; --ii) {
-      const int i = c0 + ii;
-      double u0 = 0, u1 = 0, u2 = 0;
-      if (act) {
-        u0 = X[(3 * (int64_t)i) * ld];
-        u1 = X[(3 * (int64_t)i + 1) * ld];
-        u2 = X[(3 * (int64_t)i + 2) * ld];
+    for (int b1 = cnt; b1 > 0; b1 -= 8) {   // poses b1-1 .. b1-8 of the chunk, their loads issued together
+      double tl[8][3];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = c0 + max(b1 - 1 - u, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tl[u][c] = act ? X[(3 * (int64_t)i + c) * ld] : 0.0;
       }
-      const double* G = gb + ii * 9;
-      u0 += G[0] * ti0 + G[1] * ti1 + G[2] * ti2;
-      u1 += G[3] * ti0 + G[4] * ti1 + G[5] * ti2;
-      u2 += G[6] * ti0 + G[7] * ti1 + G[8] * ti2;
-      const double* F = fb + ii * DLR_REC;
-      const double* Wn = fb + (ii + 1) * DLR_REC;
-      const double n0 = F[9] * u0 + F[10] * u1 + F[11] * u2 - (Wn[0] * z0 + Wn[3] * z1 + Wn[6] * z2);
-      const double n1 = F[10] * u0 + F[12] * u1 + F[13] * u2 - (Wn[1] * z0 + Wn[4] * z1 + Wn[7] * z2);
-      const double n2 = F[11] * u0 + F[13] * u1 + F[14] * u2 - (Wn[2] * z0 + Wn[5] * z1 + Wn[8] * z2);
-      z0 = n0; z1 = n1; z2 = n2;
-      if (act) {
-        X[(3 * (int64_t)i) * ld] = z0;
-        X[(3 * (int64_t)i + 1) * ld] = z1;
-        X[(3 * (int64_t)i + 2) * ld] = z2;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ii = b1 - 1 - u;
+        if (ii >= 0) {
+          const int i = c0 + ii;
+          const double* G = gb + ii * 9;
+          const double u0 = tl[u][0] + (G[0] * ti0 + G[1] * ti1 + G[2] * ti2);
+          const double u1 = tl[u][1] + (G[3] * ti0 + G[4] * ti1 + G[5] * ti2);
+          const double u2 = tl[u][2] + (G[6] * ti0 + G[7] * ti1 + G[8] * ti2);
+          const double* F = fb + ii * DLR_REC;
+          const double* Wn = fb + (ii + 1) * DLR_REC;
+          const double n0 = F[9] * u0 + F[10] * u1 + F[11] * u2 - (Wn[0] * z0 + Wn[3] * z1 + Wn[6] * z2);
+          const double n1 = F[10] * u0 + F[12] * u1 + F[13] * u2 - (Wn[1] * z0 + Wn[4] * z1 + Wn[7] * z2);
+          const double n2 = F[11] * u0 + F[13] * u1 + F[14] * u2 - (Wn[2] * z0 + Wn[5] * z1 + Wn[8] * z2);
+          z0 = n0; z1 = n1; z2 = n2;
+          if (act) {
+            X[(3 * (int64_t)i) * ld] = z0;
+            X[(3 * (int64_t)i + 1) * ld] = z1;
+            X[(3 * (int64_t)i + 2) * ld] = z2;
+          }
+        }
       }
     }
   }
@@ -417,12 +423,25 @@ __global__ __launch_bounds__(256) void k_dlr_fix(DlrColsArgs A) {
     const double n2 = e[2 * ld] + F[6] * x0 + F[7] * x1 + F[8] * x2;
     x0 = n0; x1 = n1; x2 = n2;
   }
-#pragma unroll 4
-  for (int i = i0; i < i1; ++i) {
-    const double* G = A.pre + (int64_t)i * DLR_PRE + 9;
-    X[(3 * (int64_t)i) * ld] += G[0] * x0 + G[1] * x1 + G[2] * x2;
-    X[(3 * (int64_t)i + 1) * ld] += G[3] * x0 + G[4] * x1 + G[5] * x2;
-    X[(3 * (int64_t)i + 2) * ld] += G[6] * x0 + G[7] * x1 + G[8] * x2;
+  // every pose's update is independent of the others: 8 poses' loads are issued before the first of them is used
+  for (int b0 = i0; b0 < i1; b0 += 8) {
+    double v[8][3];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(b0 + u, i1 - 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[u][c] = X[(3 * (int64_t)i + c) * ld];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = b0 + u;
+      if (i < i1) {
+        const double* G = A.pre + (int64_t)i * DLR_PRE + 9;
+        X[(3 * (int64_t)i) * ld] = v[u][0] + (G[0] * x0 + G[1] * x1 + G[2] * x2);
+        X[(3 * (int64_t)i + 1) * ld] = v[u][1] + (G[3] * x0 + G[4] * x1 + G[5] * x2);
+        X[(3 * (int64_t)i + 2) * ld] = v[u][2] + (G[6] * x0 + G[7] * x1 + G[8] * x2);
+      }
+    }
   }
 }
 
@@ -463,7 +482,7 @@ __global__ __launch_bounds__(256) void k_dlr_cap(DlrArgs A) {
 //   type 1 workgroups (block column k < kb of row kb of N):  N_kb,k = -L_kk^-1 sum_{j=k}^{kb-1} L_kb,j N_jk
 // Workgroup 0 stores L_kk^-1 = N_kk.
 constexpr int CHOL_T = 32 * 33;                                 // doubles of a padded 32 x 32 LDS tile
-constexpr int CHOL_LDS_DOUBLES = 2 * CHOL_T + 32 + 8 * CHOL_T + 64;  // Dm | Li | dinv | 4 waves x (A | B) tiles | column buffer
+constexpr int CHOL_LDS_DOUBLES = 2 * CHOL_T + 32 + 8 * CHOL_T;  // Dm | Li | dinv | 4 waves x (A | B) tiles
 constexpr size_t CHOL_LDS_BYTES = (size_t)CHOL_LDS_DOUBLES * sizeof(double);
 constexpr int CHOL_THREADS = 320;
 
@@ -493,54 +512,47 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
   if (w == 4) {
-    // ---- diagonal block: L_kk (Dm) and its inverse (Li), one wavefront.  Lane r holds row r in registers; each step's
-    // column of L is handed to the other rows through LDS as ONE write + a batch of independent broadcast reads, so the
-    // 32-step dependency chain is sqrt, divide, one LDS round trip and one FMA per step (a form with every element
-    // in LDS took 60 us per launch, one with v_readlane broadcasts 40 us)
-    double* colb = sm + 2 * CHOL_T + 32 + 8 * CHOL_T;   // 64 doubles behind the tiles
+    // ---- diagonal block: L_kk (Dm) and its inverse (Li), one wavefront: L D L' and the inverse of the unit triangle in
+    // ONE 32-step loop with the rows of both in registers (lane r: row r of the block and row r of N), v_readlane
+    // broadcasts only.  Step k scales column k, updates the trailing entries a_rc -= Lt_rk (Lt_ck D_k), c > k, and
+    // eliminates column k from the inverse, N_r. -= Lt_rk N_k. (row k of N is final by then).  No LDS access and no
+    // sqrt / divide inside the chain (one v_rcp_f64 + two Newton steps per pivot); L = Lt sqrt(D), N = sqrt(D)^-1 Lt^-1
+    // afterwards.  scripts/micro/diag32.hip measured the alternatives on one 32 x 32 block: this form 11.7 us, rows in
+    // registers + inverse through LDS 22.8 us, 256 threads with everything in LDS and workgroup barriers 19.6 us,
+    // one wavefront with everything in LDS 49 us.
     for (int e = lane; e < 1024; e += 64) Dm[(e >> 5) * 33 + (e & 31)] = dwork[(int64_t)kb * 1024 + e];
     wave_lds_sync();
     const int row = lane & 31;
-    double a[32];
+    double a[32], n[32];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) a[c] = Dm[row * 33 + c];
+    for (int c = 0; c < 32; ++c) {
+      a[c] = Dm[row * 33 + c];
+      n[c] = (c == row) ? 1.0 : 0.0;
+    }
+    double dsel = 1.0;
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
-      double* cb = colb + 32 * (k & 1);
-      if (lane == k) cb[k] = a[k];            // pivot
-      wave_lds_sync();
-      const double d = sqrt(cb[k]);
-      const double rs = 1.0 / d;
-      a[k] = (row == k) ? d : a[k] * rs;      // column k of L below the diagonal (rows above k: unused values)
-      if (lane < 32 && lane > k) cb[lane] = a[k];
-      wave_lds_sync();
+      const double d = readlane_f64(a[k], k);
+      double rd = __builtin_amdgcn_rcp(d);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      dsel = (row == k) ? d : dsel;
+      const double ak = a[k];
+      const double l = (row > k) ? ak * rd : 0.0;   // Lt_rk (0 on and above the diagonal: those rows are finished)
+      a[k] = l;
 #pragma unroll
-      for (int c = k + 1; c < 32; ++c) a[c] -= a[k] * cb[c];
+      for (int c = k + 1; c < 32; ++c) a[c] -= l * readlane_f64(ak, c);
+#pragma unroll
+      for (int c = 0; c <= k; ++c) n[c] -= l * readlane_f64(n[c], k);
     }
-    // L -> LDS (lower triangle, zeros above), reciprocal diagonal
+    const double sd = sqrt(dsel), isd = 1.0 / sd;
+    wave_lds_sync();
     if (lane < 32) {
-      double dsel = 0.0;
 #pragma unroll
       for (int c = 0; c < 32; ++c) {
-        Dm[row * 33 + c] = (c <= row) ? a[c] : 0.0;
-        dsel = (row == c) ? a[c] : dsel;
-      }
-      dinv[row] = 1.0 / dsel;
-    }
-    wave_lds_sync();
-    // column `row` of the inverse, in LDS: Li[r][c] = -(sum_{k=c}^{r-1} L[r][k] Li[k][c]) / L[r][r]; the L entries are
-    // broadcast reads, the lane's own earlier results come back from its LDS column (conflict-free: stride 1 over lanes)
-    if (lane < 32) {
-      for (int r = 0; r < 32; ++r) Li[r * 33 + row] = (r == row) ? dinv[r] : 0.0;
-      for (int r = 1; r < 32; ++r) {
-        double s0 = 0.0, s1 = 0.0;
-        int k = 0;
-        for (; k + 1 < r; k += 2) {
-          s0 += Dm[r * 33 + k] * Li[k * 33 + row];
-          s1 += Dm[r * 33 + k + 1] * Li[(k + 1) * 33 + row];
-        }
-        if (k < r) s0 += Dm[r * 33 + k] * Li[k * 33 + row];
-        if (r > row) Li[r * 33 + row] = -(s0 + s1) * dinv[r];   // (entries above the lane's diagonal stay 0, so k < row adds 0)
+        const double sc = readlane_f64(sd, c);
+        Dm[row * 33 + c] = (c < row) ? a[c] * sc : ((c == row) ? sd : 0.0);
+        Li[row * 33 + c] = n[c] * isd;
       }
     }
   } else if (has_work) {
