@@ -276,12 +276,16 @@ def test_direct_solve_eligibility(pgo):
     assert pgo.Solver(gi, pgo.Options(method=1, pcg_rtol=0.1)).info().linear_solver == 1          # inexact steps were asked for
     assert pgo.Solver(gi, pgo.Options(method=1, pcg_chain_len=64)).info().linear_solver == 1      # the caller chose a preconditioner
     assert pgo.Solver(gi, pgo.Options(method=2)).info().linear_solver == 1                        # switches: PCG
-    for name in ("M3500", "FRH"):                                                                  # too many edges outside the chain
+    for name in ("M3500", "FRH"):                             # many edges outside the chain: auto stays with PCG, forcing works
         g = load(pgo, name)
         assert pgo.Solver(g, pgo.Options(method=1)).info().linear_solver == 1
-        with pytest.raises(pgo.PgoError) as e:
-            pgo.Solver(g, pgo.Options(method=1, linear_solver=2))
-        assert e.value.status == -8   # PGO_ERR_UNSUPPORTED
+    s = pgo.Solver(load(pgo, "FRH"), pgo.Options(method=1, linear_solver=2, max_iters=3))
+    assert s.info().linear_solver == 2 and s.info().direct_rank == 3 * 1505
+    assert s.solve().iterations == 3 and s.iter_records()[1]["pcg_rel_residual"] < 1e-6
+    s.close()
+    with pytest.raises(pgo.PgoError) as e:                    # 2138 edges outside the chain: beyond the dense solve's limit
+        pgo.Solver(load(pgo, "M3500", 184), pgo.Options(method=1, linear_solver=2))
+    assert e.value.status == -8   # PGO_ERR_UNSUPPORTED
     with pytest.raises(pgo.PgoError):
         pgo.Solver(gi, pgo.Options(method=1, linear_solver=2, fixed_pose=-1))                      # nothing anchors the chain
     with pytest.raises(pgo.PgoError):

@@ -983,7 +983,9 @@ int pgo_handle::lm_begin() {
 // one rank, METHOD 0 / 1, a constant pose, an edge between every pair of consecutive poses, and few enough other edges.
 namespace {
 constexpr int DIRECT_MAX_POSES = 16384;
-constexpr int DIRECT_MAX_RANK = 1024;   // 3 x (edges outside the chain) + 1: order of the dense capacitance matrix (k_chol_solve: <= 32 blocks)
+constexpr int DIRECT_MAX_RANK = 6144;   // 3 x (edges outside the chain) + 1: order of the dense capacitance matrix
+constexpr int DIRECT_AUTO_RANK = 2048;  // auto takes the direct solve up to this rank (INTEL + 50: 918 -> 1.5 ms per LM iteration; FRH, 4515: 13 ms
+                                        // against 29 ms of PCG, but one refinement step leaves 5e-8 there; M3500, 5862: 22 ms, the same as PCG)
 }  // namespace
 
 int pgo_handle::direct_setup(int32_t N) {
@@ -1019,6 +1021,7 @@ int pgo_handle::direct_setup(int32_t N) {
     if (chain[i] < 0) return no("poses " + std::to_string(i) + " and " + std::to_string(i + 1) + " are not joined by an edge");
   dl_m = (int)lr.size();
   dl_K = 3 * dl_m;
+  if (want == 0 && dl_K > DIRECT_AUTO_RANK) return PGO_OK;   // beyond this the dense Cholesky costs what PCG costs (M3500: 22 ms either way)
   if (dl_K + 1 > DIRECT_MAX_RANK) return no(std::to_string(dl_m) + " edges outside the odometry chain (at most " + std::to_string((DIRECT_MAX_RANK - 1) / 3) + ")");
   dl_Kp = std::max(dev::CHOL_NB, ((dl_K + dev::CHOL_NB - 1) / dev::CHOL_NB) * dev::CHOL_NB);
   dl_ld = ((dl_K + 1 + 63) / 64) * 64;

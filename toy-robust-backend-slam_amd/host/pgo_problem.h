@@ -99,7 +99,8 @@ class Problem {
 namespace Solver {
 struct Options {
   bool minimizer_progress_to_stdout = false;
-  LinearSolverType linear_solver_type = SPARSE_NORMAL_CHOLESKY;  // accepted; solved by block-Jacobi PCG to pcg_rtol
+  LinearSolverType linear_solver_type = SPARSE_NORMAL_CHOLESKY;  // = the library's exact solve: the direct chain + low-rank solve where it applies
+                                                                 // (INTEL, MIT, CSAIL, FR079 ...), else PCG to pcg_rtol; BLOCK_JACOBI_PCG: always PCG
   int max_num_iterations = 50;
   double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   double initial_trust_region_radius = 1e4;
@@ -166,6 +167,7 @@ struct SolverAccess {
     o.ptol = opt.parameter_tolerance;
     o.radius0 = opt.initial_trust_region_radius;
     o.pcg_rtol = opt.pcg_rtol;
+    o.linear_solver = opt.linear_solver_type == BLOCK_JACOBI_PCG ? 1 : 0;
     o.pcg_max_iters = opt.pcg_max_iters;
     o.verbose = opt.minimizer_progress_to_stdout ? 1 : 0;
     pgo_t* h = nullptr;
@@ -237,6 +239,7 @@ struct SolverAccess {
         o.ptol = opt.parameter_tolerance;
         o.radius0 = opt.initial_trust_region_radius;
         o.pcg_rtol = opt.pcg_rtol;
+        o.linear_solver = opt.linear_solver_type == BLOCK_JACOBI_PCG ? 1 : 0;
         o.pcg_max_iters = opt.pcg_max_iters;
         int st = pgo_batch_create(&b, (int32_t)prs.size(), gs.data(), &o, opt.device);
         if (st != PGO_ERR_UNSUPPORTED) {
