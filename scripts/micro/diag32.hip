@@ -180,6 +180,45 @@ __device__ void diag_v7(double* Dm, double* Li, int lane) {
     }
   }
 }
+
+__device__ __forceinline__ double bperm_f64(double v, int src_lane) {   // LDS-crossbar broadcast (no SGPR round trip)
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// variant 8: variant 7 with ds_bpermute broadcasts
+__device__ void diag_v8(double* Dm, double* Li, int lane) {
+  const int row = lane & 31;
+  double a[32], n[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    a[c] = Dm[row * 33 + c];
+    n[c] = (c == row) ? 1.0 : 0.0;
+  }
+  double dsel = 1.0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const double d = bperm_f64(a[k], k);
+    const double rd = fast_rcp(d);
+    dsel = (row == k) ? d : dsel;
+    const double ak = a[k];
+    const double l = (row > k) ? ak * rd : 0.0;
+    a[k] = l;
+#pragma unroll
+    for (int c = k + 1; c < 32; ++c) a[c] -= l * bperm_f64(ak, c);
+#pragma unroll
+    for (int c = 0; c <= k; ++c) n[c] -= l * bperm_f64(n[c], k);
+  }
+  const double sd = sqrt(dsel), isd = 1.0 / sd;
+  if (lane < 32) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const double sc = bperm_f64(sd, c);
+      Dm[row * 33 + c] = (c < row) ? a[c] * sc : ((c == row) ? sd : 0.0);
+      Li[row * 33 + c] = n[c] * isd;
+    }
+  }
+}
 template <int V>
 __global__ __launch_bounds__(V == 2 ? 256 : 64) void k_diag(const double* in, double* outL, double* outI, int reps) {
   __shared__ double Dm[32 * 33], Li[32 * 33], dinv[32], colb[64];
@@ -214,6 +253,8 @@ __global__ __launch_bounds__(V == 2 ? 256 : 64) void k_diag(const double* in, do
       diag_v4<0>(Dm, Li, lane);
     } else if (V == 7) {
       diag_v7(Dm, Li, lane);
+    } else if (V == 8) {
+      diag_v8(Dm, Li, lane);
     } else if (V == 5) {
       diag_v4<1>(Dm, Li, lane);
     } else if (V == 6) {
@@ -281,7 +322,7 @@ int main() {
   hipMemcpy(dA, A.data(), 8192, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int reps = 200;
-  for (int v = 4; v < 8; ++v) {
+  for (int v = 7; v < 9; ++v) {
     for (int pass = 0; pass < 2; ++pass) {
       hipEventRecord(e0);
       if (v == 0) hipLaunchKernelGGL(k_diag<0>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
@@ -292,6 +333,7 @@ int main() {
       if (v == 5) hipLaunchKernelGGL(k_diag<5>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
       if (v == 6) hipLaunchKernelGGL(k_diag<6>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
       if (v == 7) hipLaunchKernelGGL(k_diag<7>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
+      if (v == 8) hipLaunchKernelGGL(k_diag<8>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
       hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -343,17 +343,25 @@ __global__ __launch_bounds__(256) void k_dlr_mid(DlrColsArgs A) {
   double* __restrict__ X = A.X + col;
   // t entering this segment: t_in(q + 1) = E(q) + F_q t_in(q),  F_q = G at the last pose of segment q
   double ti0 = 0, ti1 = 0, ti2 = 0;
-  for (int q = 0; q < s; ++q) {
-    const double* F = A.pre + (int64_t)(min(n, (q + 1) * A.seglen) - 1) * DLR_PRE;
-    double e0 = 0, e1 = 0, e2 = 0;
-    if (act) {
-      const double* e = A.E + (int64_t)q * 3 * ld + col;
-      e0 = e[0]; e1 = e[ld]; e2 = e[2 * ld];
+  for (int q0 = 0; q0 < s; q0 += 8) {   // 8 segments' end states requested together (the chain over q is 3 FMAs per step)
+    double ev[8][3];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double* e = A.E + (int64_t)min(q0 + u, s - 1) * 3 * ld + col;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ev[u][c] = act ? e[c * ld] : 0.0;
     }
-    const double n0 = e0 + F[0] * ti0 + F[1] * ti1 + F[2] * ti2;
-    const double n1 = e1 + F[3] * ti0 + F[4] * ti1 + F[5] * ti2;
-    const double n2 = e2 + F[6] * ti0 + F[7] * ti1 + F[8] * ti2;
-    ti0 = n0; ti1 = n1; ti2 = n2;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u;
+      if (q < s) {
+        const double* F = A.pre + (int64_t)(min(n, (q + 1) * A.seglen) - 1) * DLR_PRE;
+        const double n0 = ev[u][0] + F[0] * ti0 + F[1] * ti1 + F[2] * ti2;
+        const double n1 = ev[u][1] + F[3] * ti0 + F[4] * ti1 + F[5] * ti2;
+        const double n2 = ev[u][2] + F[6] * ti0 + F[7] * ti1 + F[8] * ti2;
+        ti0 = n0; ti1 = n1; ti2 = n2;
+      }
+    }
   }
   double z0 = 0, z1 = 0, z2 = 0;
   const int n_chunks = (i1 - i0 + CH - 1) / CH;
@@ -415,13 +423,25 @@ __global__ __launch_bounds__(256) void k_dlr_fix(DlrColsArgs A) {
   double* __restrict__ X = A.X + col;
   // x entering this segment from the right: x_in(q - 1) = E2(q) + Fb_q x_in(q),  Fb_q = Gb at the first pose of segment q
   double x0 = 0, x1 = 0, x2 = 0;
-  for (int q = A.nseg - 1; q > s; --q) {
-    const double* F = A.pre + (int64_t)(q * A.seglen) * DLR_PRE + 9;
-    const double* e = A.E2 + (int64_t)q * 3 * ld + col;
-    const double n0 = e[0] + F[0] * x0 + F[1] * x1 + F[2] * x2;
-    const double n1 = e[ld] + F[3] * x0 + F[4] * x1 + F[5] * x2;
-    const double n2 = e[2 * ld] + F[6] * x0 + F[7] * x1 + F[8] * x2;
-    x0 = n0; x1 = n1; x2 = n2;
+  for (int q0 = A.nseg - 1; q0 > s; q0 -= 8) {   // 8 segments' start states requested together
+    double ev[8][3];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double* e = A.E2 + (int64_t)max(q0 - u, s + 1) * 3 * ld + col;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ev[u][c] = e[c * ld];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 - u;
+      if (q > s) {
+        const double* F = A.pre + (int64_t)(q * A.seglen) * DLR_PRE + 9;
+        const double n0 = ev[u][0] + F[0] * x0 + F[1] * x1 + F[2] * x2;
+        const double n1 = ev[u][1] + F[3] * x0 + F[4] * x1 + F[5] * x2;
+        const double n2 = ev[u][2] + F[6] * x0 + F[7] * x1 + F[8] * x2;
+        x0 = n0; x1 = n1; x2 = n2;
+      }
+    }
   }
   // every pose's update is independent of the others: 8 poses' loads are issued before the first of them is used
   for (int b0 = i0; b0 < i1; b0 += 8) {
