@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--passes", type=int, default=3, help="timed passes of W + K LM iterations from the initial poses; the median is reported")
+    ap.add_argument("--passes", type=int, default=5, help="timed passes of W + K LM iterations from the initial poses; the median is reported")
     ap.add_argument("--poses", type=int, default=1_000_000)
     ap.add_argument("--pcg-rtol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=500)
@@ -340,6 +340,23 @@ def main():
                     "value": n1 / it1, "unit": "iter/s", "cores": 1,
                     "sample": "LM iteration(s) 1..%d of the same workload, the same port with threads = 1 (the reference runs Ceres "
                               "with its default num_threads = 1); %.1f s incl. first linearisation" % (n1, t1)}
+
+            # the reference's own workload (BASELINE configs[0]: INTEL + 50 outlier loops, Ceres SPARSE_NORMAL_CHOLESKY on
+            # one thread): here a sparse direct factorisation IS the right CPU baseline -- the oracle's direct-solve LM
+            # (scipy SuperLU standing in for Ceres' CHOLMOD path, 1 thread), whole 50-iteration solves
+            if args.workloads:
+                try:
+                    gi_o = O.add_random_C(O.read_g2o(os.path.join(ROOT, "tests", "golden", "data", "INTEL.g2o")), 50, 1)
+                    intel = {}
+                    for m in (1, 0):
+                        tc = time.perf_counter()
+                        r_o = O.lm_direct(gi_o, O.Options(method=m))
+                        intel["METHOD %d" % m] = {"gn_it_per_s": r_o.iterations / (time.perf_counter() - tc), "iterations": r_o.iterations,
+                                                 "final_cost": r_o.final_cost}
+                    out["cpu_baseline"]["intel_plus_50_direct_solve"] = dict(
+                        intel, cores=1, kind="port", solver="oracle.lm_direct: the same LM policy, normal equations by scipy SuperLU")
+                except Exception as e:
+                    out["cpu_baseline"]["intel_plus_50_direct_solve"] = {"error": repr(e)}
 
         # ---- the other workloads north_star names (N = 1): whole 50-iteration solves, GN it/s = iterations / solve seconds
         if world == 1 and args.workloads:

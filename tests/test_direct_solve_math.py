@@ -128,3 +128,40 @@ def test_woodbury_chain_plus_low_rank_equals_sparse_direct_solve(oracle, method,
     e1 = np.linalg.norm(y - y_ref) / np.linalg.norm(y_ref)
     print(f"METHOD {method} radius {radius:.0e}: rank {K}, relative error {e0:.1e} -> {e1:.1e} after one refinement step")
     assert e0 < 1e-4 and e1 < 1e-8
+
+
+@pytest.mark.parametrize("radius", [1e4, 1e16])
+def test_separators_restore_the_whole_chain(oracle, radius):
+    """k_dlr_sep_*: the chain is factorised in 4 pieces side by side (nested dissection with 3 separator poses).  With
+    Tt = T without the separators' couplings (what the sweeps invert), B those couplings, Ms the separators' diagonal blocks:
+    x_s = S^-1 (Ms z_s - B' z_p), x_p = z_p - Y x_s, z = Tt^-1 r, Y = Tt^-1 B, S = Ms - B' Y (SPD, order 9)"""
+    g, As, H, D2, gs = _system(oracle, "INTEL", 50, 1, radius)
+    rows_c = np.repeat(_chain_split(g), 3)
+    Ac = As[rows_c]
+    Td = (Ac.T @ Ac + sp.diags(D2)).toarray()
+    n = Td.shape[0] // 3
+    seps = [(k * n) // 4 for k in (1, 2, 3)]
+    Tt = Td.copy()
+    B = np.zeros((3 * n, 9))
+    srow = np.concatenate([np.arange(3 * s, 3 * s + 3) for s in seps])
+    for j, s in enumerate(seps):
+        B[3 * s - 3:3 * s, 3 * j:3 * j + 3] = Td[3 * s - 3:3 * s, 3 * s:3 * s + 3]          # C_s'
+        B[3 * s + 3:3 * s + 6, 3 * j:3 * j + 3] = Td[3 * s + 3:3 * s + 6, 3 * s:3 * s + 3]  # C_{s+1}
+        for (r0, c0) in ((s, s - 1), (s - 1, s), (s + 1, s), (s, s + 1)):
+            Tt[3 * r0:3 * r0 + 3, 3 * c0:3 * c0 + 3] = 0.0
+    assert np.linalg.eigvalsh(Tt)[0] > 1e-9                     # the pieces stay anchored: every diagonal block keeps all its edges
+    lu = spla.splu(sp.csc_matrix(Tt))
+    rhs = np.random.default_rng(1).standard_normal((3 * n, 4))
+    rhs[:, 0] = gs
+    z, Y = lu.solve(rhs), lu.solve(B)
+    assert np.abs(Y[srow]).max() == 0.0
+    Ms = Td[np.ix_(srow, srow)]
+    S = Ms - B.T @ Y
+    assert np.linalg.eigvalsh(0.5 * (S + S.T))[0] > 0.0
+    w = np.linalg.solve(S, Ms @ z[srow] - B.T @ z)
+    x = z - Y @ w
+    x[srow] = w
+    ref = spla.splu(sp.csc_matrix(Td)).solve(rhs)
+    err = np.abs(x - ref).max() / np.abs(ref).max()
+    print(f"radius {radius:.0e}: 3 separators, Schur complement condition {np.linalg.cond(S):.1e}, relative error of T^-1 r {err:.1e}")
+    assert err < 1e-7

@@ -29,6 +29,7 @@ constexpr int DLR_REC = 16;  // doubles per pose: input record M (6: 00 01 02 11
                              // factor record W (9, row-major) | S^-1 (6) | pad
 constexpr int DLR_V = 18;    // doubles per low-rank edge: Xa (9) | Xb (9), X[k][c] = d e_k / d (pose)_c * scale_c
 constexpr int CHOL_NB = 32;
+constexpr int DLR_MAX_SEP = 3;   // separator poses: the chain factorisation runs nsep + 1 = 4 pieces side by side
 
 struct DlrArgs {
   int32_t n;                  // poses
@@ -52,6 +53,10 @@ struct DlrArgs {
   double* cap;                // [Kp][Kp]
   double* dwork;              // [Kp / 32][32][32]: the diagonal blocks of the capacitance matrix, updated by k_chol_panel
   double* cvec;               // [Kp]
+  // separators of the chain (k_dlr_factor runs the pieces between them side by side, see k_dlr_sep_*)
+  int32_t nsep;
+  int32_t sep[DLR_MAX_SEP];
+  double* ksep;               // [nsep][18]: the couplings taken out of T: C_s = T[s][s-1] (9) | C_{s+1} = T[s+1][s] (9)
 };
 
 // scaled Jacobian blocks of edge e (record layout: kernels.hip.h REC; the second block is implied)
@@ -104,12 +109,23 @@ __global__ void k_dlr_setup(DlrArgs A) {
           for (int c = 0; c < 3; ++c) C[3 * r + c] = Xi[r] * Xo[c] + Xi[3 + r] * Xo[3 + c] + Xi[6 + r] * Xo[6 + c];
       }
     }
+    // separator s: the couplings (s, s-1) and (s+1, s) leave T (they come back through k_dlr_sep_*), so that the chain
+    // falls into independently factorised pieces; the diagonal blocks keep every edge's contribution (anchored pieces)
+    int cut = -1;
+    for (int j = 0; j < A.nsep; ++j) {
+      if (i == A.sep[j]) cut = 2 * j;
+      if (i == A.sep[j] + 1) cut = 2 * j + 1;
+    }
     double* o = A.trec + (int64_t)i * DLR_REC;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = M[k];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o[6 + k] = C[k];
+    for (int k = 0; k < 9; ++k) o[6 + k] = cut >= 0 ? 0.0 : C[k];
     o[15] = 0.0;
+    if (cut >= 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) A.ksep[(int64_t)cut * 9 + k] = C[k];
+    }
   } else if (idx < A.n + A.m) {
     const int j = idx - A.n;
     const int e = A.lr_edge[j];
@@ -128,10 +144,16 @@ __global__ void k_dlr_setup(DlrArgs A) {
 // Block LDL' of the block-tridiagonal T, one wavefront (every lane runs the same recurrence; lane 0 stores).  The input
 // records pass through LDS in chunks of 128 poses, the next chunk is fetched while the current one is factorised: the
 // 3x3 recurrence itself (a cofactor inverse and two 3x3 products per pose, ~0.1 us) is the critical path.
-__global__ __launch_bounds__(64) void k_dlr_factor(const double* __restrict__ trec, int n, double* __restrict__ fac) {
+__global__ __launch_bounds__(64) void k_dlr_factor(const double* __restrict__ trec_all, int n_all, double* __restrict__ fac_all, DlrArgs A) {
   constexpr int CH = 128;
   __shared__ double buf[2][CH * DLR_REC];
   const int lane = threadIdx.x;
+  // piece b = [start, end): pieces begin at a separator (C = 0 there AND at the next pose, so the recurrence restarts twice)
+  const int start = blockIdx.x == 0 ? 0 : A.sep[blockIdx.x - 1];
+  const int end = (int)blockIdx.x < A.nsep ? A.sep[blockIdx.x] : n_all;
+  const int n = end - start;
+  const double* __restrict__ trec = trec_all + (int64_t)start * DLR_REC;
+  double* __restrict__ fac = fac_all + (int64_t)start * DLR_REC;
   const int n_chunks = (n + CH - 1) / CH;
   const int64_t total = (int64_t)n * DLR_REC;
   for (int k = 0; k < CH * DLR_REC / 64; ++k) {
@@ -210,6 +232,9 @@ struct DlrColsArgs {
   const double* fac;
   const double* pre;
   int32_t n, ncols, K, vec_col, ld, nseg, seglen;
+  int32_t ucol0, nsep;         // columns ucol0 .. ucol0 + 3 nsep - 1: the couplings of the separator poses (k_dlr_sep_*)
+  int32_t sep[DLR_MAX_SEP];
+  const double* ksep;
   const double* vrec;
   const int32_t* va;
   const int32_t* vb;
@@ -281,6 +306,14 @@ __device__ __forceinline__ DlrCol dlr_col(const DlrColsArgs& A, int col) {
     const double* v = A.vrec + (int64_t)j * DLR_V + 3 * k;
     c.ra0 = v[0]; c.ra1 = v[1]; c.ra2 = v[2];
     c.rb0 = v[9]; c.rb1 = v[10]; c.rb2 = v[11];
+  } else if (c.act && !c.isvec && col >= A.ucol0 && col < A.ucol0 + 3 * A.nsep) {
+    // column (j, k) of B = the part of T's column 3 s_j + k that lies in the pieces: C_s'[:, k] at pose s - 1, C_{s+1}[:, k] at s + 1
+    const int u = col - A.ucol0, j = u / 3, k = u - 3 * j;
+    const double* ks = A.ksep + (int64_t)j * 18;
+    c.a = A.sep[j] - 1;
+    c.b = A.sep[j] + 1;
+    c.ra0 = ks[3 * k]; c.ra1 = ks[3 * k + 1]; c.ra2 = ks[3 * k + 2];
+    c.rb0 = ks[9 + k]; c.rb1 = ks[12 + k]; c.rb2 = ks[15 + k];
   }
   return c;
 }
@@ -460,6 +493,168 @@ __global__ __launch_bounds__(256) void k_dlr_fix(DlrColsArgs A) {
         X[(3 * (int64_t)i) * ld] = v[u][0] + (G[0] * x0 + G[1] * x1 + G[2] * x2);
         X[(3 * (int64_t)i + 1) * ld] = v[u][1] + (G[3] * x0 + G[4] * x1 + G[5] * x2);
         X[(3 * (int64_t)i + 2) * ld] = v[u][2] + (G[6] * x0 + G[7] * x1 + G[8] * x2);
+      }
+    }
+  }
+}
+
+// ---- the couplings taken out at the separators come back here: nested dissection of the chain.  With the poses ordered
+// (pieces, separators),  T = [[Tp, B], [B', Ms]]  where Tp = the pieces (what k_dlr_factor factorised; the batched sweeps
+// apply Tt^-1 = blockdiag(Tp^-1, Ms^-1)), B = the couplings C_s, C_{s+1} and Ms = the separators' diagonal blocks:
+//     x_s = S^-1 (Ms z_s - B' z_p),   x_p = z_p - Y x_s,      z = Tt^-1 r,   Y = Tp^-1 B,   S = Ms - B' Y
+// S (order 3 nsep <= 9) is a Schur complement of the SPD T: SPD, inverted without pivoting.  Y = 3 nsep more columns
+// of the batched solve (zero on the separator rows); S^-1 once per factorisation; then every other column j:
+//     k_dlr_sep_w      w_j = S^-1 (Ms z_s - C_s z_{s-1} - C_{s+1}' z_{s+1})
+//     k_dlr_sep_apply  z_j -= Y w_j on the piece rows,  z_j = w_j on the separator rows
+// (a first form restored the couplings as an indefinite low-rank term, T = Tt + U K U', order 27 with pivoting: 72 us for
+// the reduced system alone)
+constexpr int DLR_MAX_U = 3 * DLR_MAX_SEP;
+struct DlrSepArgs {
+  int32_t nsep, nU, n;
+  int32_t sep[DLR_MAX_SEP];
+  const double* ksep;   // [nsep][18]: C_s (9) | C_{s+1} (9), row-major
+  const double* trec;   // pose records: Ms = trec[s][0..5]
+  const double* Y;      // the B columns inside Z: Y[r * yld + u]
+  int32_t yld;
+  double* Sinv;         // [nU][nU]
+  double* X;            // the columns to correct: [3n][ld]
+  int32_t ld, ncols;
+  double* Wm;           // [nU][ld]
+};
+
+__global__ __launch_bounds__(64) void k_dlr_sep_system(DlrSepArgs A) {
+  __shared__ double Ab[DLR_MAX_U * 2 * DLR_MAX_U];   // [S | I], row stride 2 nU
+  const int tid = threadIdx.x, nU = A.nU, w2 = 2 * nU;
+  for (int e = tid; e < nU * nU; e += 64) {
+    const int u = e / nU, v = e - u * nU;
+    const int j = u / 3, c = u - 3 * j, jv = v / 3, cv = v - 3 * jv;
+    const int sp = A.sep[j];
+    const double* ks = A.ksep + (int64_t)j * 18;
+    double val = 0.0;
+    if (j == jv) {   // Ms (symmetric: 00 01 02 11 12 22)
+      const double* M = A.trec + (int64_t)sp * DLR_REC;
+      const int lo = min(c, cv), hi = max(c, cv);
+      val = M[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+    }
+    // - b_u' Y[:, v] = - sum_k C_s[c][k] Y[3 (s-1) + k][v] - sum_k C_{s+1}[k][c] Y[3 (s+1) + k][v]
+    for (int k = 0; k < 3; ++k)
+      val -= ks[3 * c + k] * A.Y[(int64_t)(3 * (sp - 1) + k) * A.yld + v] + ks[9 + 3 * k + c] * A.Y[(int64_t)(3 * (sp + 1) + k) * A.yld + v];
+    Ab[u * w2 + v] = val;
+    Ab[u * w2 + nU + v] = (u == v) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int k = 0; k < nU; ++k) {   // Gauss-Jordan, no pivoting (SPD)
+    const double pinv = 1.0 / Ab[k * w2 + k];
+    double nv[6];
+    int cnt = 0;
+    for (int e = tid; e < nU * w2; e += 64, ++cnt) {
+      const int r = e / w2, c = e - r * w2;
+      const double pk = Ab[k * w2 + c] * pinv;
+      nv[cnt] = (r == k) ? pk : Ab[e] - Ab[r * w2 + k] * pk;
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int e = tid; e < nU * w2; e += 64, ++cnt) Ab[e] = nv[cnt];
+    __syncthreads();
+  }
+  for (int e = tid; e < nU * nU; e += 64) A.Sinv[e] = Ab[(e / nU) * w2 + nU + (e % nU)];
+}
+
+// w_j = S^-1 (Ms z_s - C_s z_{s-1} - C_{s+1}' z_{s+1}) for the columns j < ncols of X
+__global__ __launch_bounds__(256) void k_dlr_sep_w(DlrSepArgs A) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= A.ncols) return;
+  const int nU = A.nU;
+  double g[DLR_MAX_U];
+#pragma unroll
+  for (int q = 0; q < DLR_MAX_SEP; ++q) {
+    if (q < A.nsep) {
+      const int sp = A.sep[q];
+      const double* ks = A.ksep + (int64_t)q * 18;
+      const double* M = A.trec + (int64_t)sp * DLR_REC;
+      double zm[3], zs[3], zp[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        zm[k] = A.X[(int64_t)(3 * (sp - 1) + k) * A.ld + j];
+        zs[k] = A.X[(int64_t)(3 * sp + k) * A.ld + j];
+        zp[k] = A.X[(int64_t)(3 * (sp + 1) + k) * A.ld + j];
+      }
+      g[3 * q] = M[0] * zs[0] + M[1] * zs[1] + M[2] * zs[2];
+      g[3 * q + 1] = M[1] * zs[0] + M[3] * zs[1] + M[4] * zs[2];
+      g[3 * q + 2] = M[2] * zs[0] + M[4] * zs[1] + M[5] * zs[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[3 * q + c] -= ks[3 * c + k] * zm[k] + ks[9 + 3 * k + c] * zp[k];
+    } else {
+      g[3 * q] = g[3 * q + 1] = g[3 * q + 2] = 0.0;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < DLR_MAX_U; ++u) {
+    if (u < nU) {
+      double s = 0.0;
+#pragma unroll
+      for (int v = 0; v < DLR_MAX_U; ++v) s += (v < nU) ? A.Sinv[u * nU + v] * g[v] : 0.0;
+      A.Wm[(int64_t)u * A.ld + j] = s;
+    }
+  }
+}
+
+// z_j -= Y w_j (piece rows; Y is zero on the separator rows), z_j = w_j on the separator rows.  A thread = one column, a
+// workgroup = 64 rows of it (w_j in registers, the rows of Y staged in LDS, 8 rows read and written at a time); with a
+// single column: one thread per row instead
+__global__ __launch_bounds__(256) void k_dlr_sep_apply(DlrSepArgs A) {
+  __shared__ double Ys[64 * DLR_MAX_U];
+  __shared__ int sepu[64];   // row -> entry of w that replaces it (-1: a piece row)
+  const int nU = A.nU;
+  const int r0 = blockIdx.y * 64, r1 = min(3 * A.n, r0 + 64);
+  if (threadIdx.x < 64) {
+    const int r = r0 + threadIdx.x, pose = r / 3;
+    int u = -1;
+    for (int q = 0; q < A.nsep; ++q)
+      if (pose == A.sep[q]) u = 3 * q + (r - 3 * pose);
+    sepu[threadIdx.x] = u;
+  }
+  for (int e = threadIdx.x; e < 64 * DLR_MAX_U; e += 256) {
+    const int rr = e / DLR_MAX_U, b = e - rr * DLR_MAX_U;
+    Ys[e] = (r0 + rr < r1 && b < nU) ? A.Y[(int64_t)(r0 + rr) * A.yld + b] : 0.0;
+  }
+  __syncthreads();
+  if (A.ncols == 1) {   // grid.x == 1: threads 0..63 take a row each
+    const int r = r0 + threadIdx.x;
+    if (threadIdx.x < 64 && r < r1) {
+      double s = 0.0;
+      for (int b = 0; b < nU; ++b) s += Ys[threadIdx.x * DLR_MAX_U + b] * A.Wm[(int64_t)b * A.ld];
+      const int u = sepu[threadIdx.x];
+      A.X[(int64_t)r * A.ld] = u >= 0 ? A.Wm[(int64_t)u * A.ld] : A.X[(int64_t)r * A.ld] - s;
+    }
+    return;
+  }
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= A.ncols) return;
+  double w[DLR_MAX_U];
+#pragma unroll
+  for (int b = 0; b < DLR_MAX_U; ++b) w[b] = (b < nU) ? A.Wm[(int64_t)b * A.ld + j] : 0.0;
+  for (int b0 = r0; b0 < r1; b0 += 8) {
+    double xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = A.X[(int64_t)min(b0 + u, r1 - 1) * A.ld + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = b0 + u;
+      if (r < r1) {
+        const double* y = Ys + (r - r0) * DLR_MAX_U;
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < DLR_MAX_U; ++b) s += y[b] * w[b];
+        const int su = sepu[r - r0];
+        double out = xv[u] - s;
+        if (su >= 0) {
+#pragma unroll
+          for (int b = 0; b < DLR_MAX_U; ++b) out = (b == su) ? w[b] : out;
+        }
+        A.X[(int64_t)r * A.ld + j] = out;
       }
     }
   }

@@ -177,6 +177,8 @@ struct pgo_handle {
   double *dl_trec = nullptr, *dl_fac = nullptr, *dl_pre = nullptr, *dl_vrec = nullptr, *dl_Z = nullptr, *dl_cap = nullptr, *dl_dwork = nullptr,
          *dl_nm = nullptr, *dl_cy = nullptr, *dl_cvec = nullptr, *dl_x1 = nullptr, *dl_E = nullptr, *dl_E2 = nullptr;
   int dl_nseg = 1, dl_seglen = 1;
+  int dl_nsep = 0, dl_sep[dev::DLR_MAX_SEP] = {0, 0, 0}, dl_nU = 0;
+  double *dl_ksep = nullptr, *dl_R = nullptr, *dl_Wm = nullptr;
   double dl_rel = 0.0;  // |g - (H + D'D) y| / |g| of the latest direct solve
 
   // LM state (TrustRegionMinimizer)
@@ -1024,7 +1026,18 @@ int pgo_handle::direct_setup(int32_t N) {
   if (want == 0 && dl_K > DIRECT_AUTO_RANK) return PGO_OK;   // beyond this the dense Cholesky costs what PCG costs (M3500: 22 ms either way)
   if (dl_K + 1 > DIRECT_MAX_RANK) return no(std::to_string(dl_m) + " edges outside the odometry chain (at most " + std::to_string((DIRECT_MAX_RANK - 1) / 3) + ")");
   dl_Kp = std::max(dev::CHOL_NB, ((dl_K + dev::CHOL_NB - 1) / dev::CHOL_NB) * dev::CHOL_NB);
-  dl_ld = ((dl_K + 1 + 63) / 64) * 64;
+  // separators: the chain is factorised in nsep + 1 pieces side by side (k_dlr_factor is one wavefront's dependent chain:
+  // 0.3 us per pose); PGO_DIRECT_SEP=0 keeps one piece
+  dl_nsep = 0;
+  {
+    const char* se = getenv("PGO_DIRECT_SEP");
+    if (N >= 256 && !(se && se[0] == '0')) {
+      dl_nsep = dev::DLR_MAX_SEP;
+      for (int j = 0; j < dl_nsep; ++j) dl_sep[j] = (int)(((int64_t)(j + 1) * N) / (dl_nsep + 1));
+    }
+  }
+  dl_nU = 3 * dl_nsep;
+  dl_ld = ((dl_K + 1 + dl_nU + 63) / 64) * 64;
   if (const char* re = getenv("PGO_DIRECT_REFINE")) dl_refine = std::max(0, atoi(re));
   PGOC(dalloc(&dl_chain_edge, N));
   PGOC(dalloc(&dl_lr_edge, std::max(1, dl_m)));
@@ -1050,6 +1063,9 @@ int pgo_handle::direct_setup(int32_t N) {
   PGOC(dalloc(&dl_E2, (int64_t)dl_nseg * 3 * dl_ld));
   HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_chol_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::CHOL_LDS_BYTES));
   PGOC(dalloc(&dl_cvec, dl_Kp));
+  PGOC(dalloc(&dl_ksep, 18 * std::max(1, dl_nsep)));
+  PGOC(dalloc(&dl_R, std::max(1, dl_nU * dl_nU)));
+  PGOC(dalloc(&dl_Wm, (int64_t)std::max(1, dl_nU) * dl_ld));
   PGOC(sync());  // the host lists die with this scope
   direct = true;
   return PGO_OK;
@@ -1081,9 +1097,12 @@ int pgo_handle::direct_solve() {
   A.cap = dl_cap;
   A.dwork = dl_dwork;
   A.cvec = dl_cvec;
+  A.nsep = dl_nsep;
+  for (int j = 0; j < dev::DLR_MAX_SEP; ++j) A.sep[j] = dl_sep[j];
+  A.ksep = dl_ksep;
   hipLaunchKernelGGL(dev::k_dlr_setup, dim3((n + dl_m + 255) / 256), dim3(256), 0, stream, A);
   PGOC(check_launch("k_dlr_setup"));
-  hipLaunchKernelGGL(dev::k_dlr_factor, dim3(1), dim3(64), 0, stream, (const double*)dl_trec, n, dl_fac);
+  hipLaunchKernelGGL(dev::k_dlr_factor, dim3(dl_nsep + 1), dim3(64), 0, stream, (const double*)dl_trec, n, dl_fac, A);
   PGOC(check_launch("k_dlr_factor"));
   hipLaunchKernelGGL(dev::k_dlr_prefix, dim3(1), dim3(64), 0, stream, (const double*)dl_fac, n, dl_nseg, dl_seglen, dl_pre);
   PGOC(check_launch("k_dlr_prefix"));
@@ -1091,10 +1110,14 @@ int pgo_handle::direct_solve() {
   C.fac = dl_fac;
   C.pre = dl_pre;
   C.n = n;
-  C.ncols = K + 1;
+  C.ncols = K + 1 + dl_nU;
   C.K = K;
   C.vec_col = K;
   C.ld = dl_ld;
+  C.ucol0 = K + 1;
+  C.nsep = dl_nsep;
+  for (int j = 0; j < dev::DLR_MAX_SEP; ++j) C.sep[j] = dl_sep[j];
+  C.ksep = dl_ksep;
   C.nseg = dl_nseg;
   C.seglen = dl_seglen;
   C.vrec = dl_vrec;
@@ -1113,6 +1136,36 @@ int pgo_handle::direct_solve() {
     return check_launch("k_dlr_fwd / _mid / _fix");
   };
   PGOC(solve_columns(C));
+  // the couplings at the separators (k_dlr_sep_*): Y = the U columns of this solve, R once per factorisation
+  dev::DlrSepArgs SA;
+  SA.nsep = dl_nsep;
+  SA.nU = dl_nU;
+  SA.n = n;
+  for (int j = 0; j < dev::DLR_MAX_SEP; ++j) SA.sep[j] = dl_sep[j];
+  SA.ksep = dl_ksep;
+  SA.Y = dl_Z + (K + 1);
+  SA.yld = dl_ld;
+  SA.Sinv = dl_R;
+  SA.trec = dl_trec;
+  SA.Wm = dl_Wm;
+  auto separator_fix = [&](double* X, int ld, int ncols) -> int {
+    if (dl_nsep == 0) return PGO_OK;
+    dev::DlrSepArgs Q = SA;
+    Q.X = X;
+    Q.ld = ld;
+    Q.ncols = ncols;
+    hipLaunchKernelGGL(dev::k_dlr_sep_w, dim3((ncols + 255) / 256), dim3(256), 0, stream, Q);
+    hipLaunchKernelGGL(dev::k_dlr_sep_apply, dim3((ncols + 255) / 256, (3 * n + 63) / 64), dim3(256), 0, stream, Q);
+    return check_launch("k_dlr_sep_w / _apply");
+  };
+  if (dl_nsep > 0) {
+    SA.X = dl_Z;
+    SA.ld = dl_ld;
+    SA.ncols = K + 1;
+    hipLaunchKernelGGL(dev::k_dlr_sep_system, dim3(1), dim3(64), 0, stream, SA);
+    PGOC(check_launch("k_dlr_sep_system"));
+  }
+  PGOC(separator_fix(dl_Z, dl_ld, K + 1));
   hipLaunchKernelGGL(dev::k_dlr_cap, dim3((std::max(Kp, K + 1) + 255) / 256, Kp), dim3(256), 0, stream, A);
   PGOC(check_launch("k_dlr_cap"));
   for (int kb = 0; kb < nb; ++kb) {
@@ -1142,7 +1195,9 @@ int pgo_handle::direct_solve() {
     C1.ld = 64;
     C1.rhs_sub = ap;
     C1.X = dl_x1;
+    C1.nsep = 0;   // (no U columns: Y and R of the main solve are reused)
     PGOC(solve_columns(C1));
+    PGOC(separator_fix(dl_x1, 64, 1));
     hipLaunchKernelGGL(dev::k_dlr_vdot, dim3((Kp + 255) / 256), dim3(256), 0, stream, A, (const double*)dl_x1, 64, 0, dl_cvec);
     PGOC(check_launch("k_dlr_vdot"));
     PGOC(capacitance_solve());
