@@ -59,7 +59,11 @@ int main(int argc, char** argv) {
   if ((int)sums.size() != n_layers) return 1;
   for (int l = 0; l < n_layers; ++l) {
     pgo::Solver::Summary s1;
-    pgo::Solve(options, single[l].problem.get(), &s1);
+    // like for like: the batched handle solves by PCG (to 1e-10); a single SPARSE_NORMAL_CHOLESKY solve would take the
+    // direct chain + low-rank path on these layers and differ from PCG at PCG's own tolerance
+    pgo::Solver::Options one = options;
+    one.linear_solver_type = pgo::BLOCK_JACOBI_PCG;
+    pgo::Solve(one, single[l].problem.get(), &s1);
     // the batched handle sums its dot products per workgroup, an ordinary handle per tile: equal up to rounding
     if (std::fabs(s1.s.final_cost - sums[l].s.final_cost) > 1e-10 * s1.s.final_cost || s1.s.iterations != sums[l].s.iterations) {
       fprintf(stderr, "layer %d: summaries differ (%.17g vs %.17g)\n", l, s1.s.final_cost, sums[l].s.final_cost);
