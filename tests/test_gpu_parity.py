@@ -313,6 +313,22 @@ def test_direct_solve_other_options_and_reproducibility(pgo, oracle):
         runs.append(s.poses())
         s.close()
     np.testing.assert_array_equal(runs[0], runs[1])
+    # chain edges given in the reverse direction (a = i + 1, b = i), and a duplicated one: the chain takes the first edge of a
+    # pair whatever its orientation, every further one is a low-rank term
+    ia, ib, kind, meas = np.array(g.ia), np.array(g.ib), np.array(g.kind), np.array(g.meas)
+    flip = [k for k in range(g.n_edges) if abs(int(ia[k]) - int(ib[k])) == 1][::7]
+    ia2, ib2 = ia.copy(), ib.copy()
+    ia2[flip], ib2[flip] = ib[flip], ia[flip]
+    ia2, ib2 = np.append(ia2, ia2[flip[3]]), np.append(ib2, ib2[flip[3]])
+    gf = pgo.Graph.from_arrays(np.array(g.poses), ia2, ib2, np.vstack([meas, meas[flip[3]:flip[3] + 1]]), np.append(kind, kind[flip[3]]))
+    res = {}
+    for ls in (2, 1):
+        s = pgo.Solver(gf, pgo.Options(method=1, max_iters=6, linear_solver=ls, pcg_rtol=1e-12, pcg_max_iters=400000))
+        sm = s.solve()
+        res[ls] = (s.poses(), sm.final_cost, [r["step_ok"] for r in s.iter_records()], s.info().direct_rank)
+        s.close()
+    assert res[2][3] == 3 * (128 + 1) and res[2][2] == res[1][2]
+    assert res[2][1] == pytest.approx(res[1][1], rel=1e-9) and np.abs(res[2][0] - res[1][0]).max() < 1e-7
     # a graph without any edge outside the chain (pure odometry): rank 0, the chain factorisation alone is the solve
     keep = [k for k in range(g.n_edges) if abs(int(g.ia[k]) - int(g.ib[k])) == 1]
     gc = pgo.Graph.from_arrays(np.array(g.poses), np.array(g.ia)[keep], np.array(g.ib)[keep], np.array(g.meas)[keep], np.array(g.kind)[keep])

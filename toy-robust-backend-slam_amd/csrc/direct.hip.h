@@ -726,6 +726,16 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  // the workgroup's own entries of C_ik and of its diagonal block are requested now, used after the accumulation
+  const int pr = (tid & 255) >> 3, pc = 4 * (tid & 7);
+  double c_own[4] = {0.0, 0.0, 0.0, 0.0}, d_own[4] = {0.0, 0.0, 0.0, 0.0};
+  if (tid < 256 && has_work && !type1) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      c_own[v] = Cm[(int64_t)(32 * i + pr) * ld + 32 * kb + pc + v];
+      d_own[v] = dwork[(int64_t)i * 1024 + pr * 32 + pc + v];
+    }
+  }
   if (w == 4) {
     // ---- diagonal block: L_kk (Dm) and its inverse (Li), one wavefront: L D L' and the inverse of the unit triangle in
     // ONE 32-step loop with the rows of both in registers (lane r: row r of the block and row r of N), v_readlane
@@ -841,14 +851,13 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
   }
   if (!has_work) return;
   double* Ps = tiles + CHOL_T;   // wave 0's B tile: P, later the result
-  const int pr = (tid & 255) >> 3, pc = 4 * (tid & 7);
   double pv[4] = {0.0, 0.0, 0.0, 0.0};
   if (tid < 256) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int o = pr * 33 + pc + v;
       const double sum = ((tiles[o] + tiles[2 * CHOL_T + o]) + tiles[4 * CHOL_T + o]) + tiles[6 * CHOL_T + o];
-      pv[v] = type1 ? sum : Cm[(int64_t)(32 * i + pr) * ld + 32 * kb + pc + v] - sum;
+      pv[v] = type1 ? sum : c_own[v] - sum;
     }
   }
   __syncthreads();
@@ -895,7 +904,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
       for (int v = 0; v < 4; ++v) dv[v] += xk * Ps[(pc + v) * 33 + k];
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) dwork[(int64_t)i * 1024 + pr * 32 + pc + v] -= dv[v];
+    for (int v = 0; v < 4; ++v) dwork[(int64_t)i * 1024 + pr * 32 + pc + v] = d_own[v] - dv[v];
   }
 }
 
