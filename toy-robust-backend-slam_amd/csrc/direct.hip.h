@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64) void k_dlr_factor(const double* __restrict__ tr
 // Column c < K is row c of V (non-zero on the two endpoint poses of its edge); column `vec_col` is the dense vector
 // rhs_b - rhs_sub (rhs_sub may be null).  One lane per column, a workgroup = 256 columns of one segment.
 constexpr int DLR_PRE = 18;   // doubles per pose of the prefix products: G (9) | Gb (9), row-major
-constexpr int DLR_MAX_SEG = 32;
+constexpr int DLR_MAX_SEG = 64;
 struct DlrColsArgs {
   const double* fac;
   const double* pre;
@@ -245,16 +245,16 @@ struct DlrColsArgs {
   double* E2;  // [nseg][3][ld]
 };
 
-// prefix products of one segment per thread: threads 0 .. nseg-1 forward (G), 32 .. 32+nseg-1 backward (Gb)
-__global__ __launch_bounds__(64) void k_dlr_prefix(const double* __restrict__ fac, int n, int nseg, int seglen, double* __restrict__ pre) {
+// prefix products of one segment per thread: threads 0 .. nseg-1 forward (G), 64 .. 64+nseg-1 backward (Gb)
+__global__ __launch_bounds__(128) void k_dlr_prefix(const double* __restrict__ fac, int n, int nseg, int seglen, double* __restrict__ pre) {
   const int t = threadIdx.x;
-  const bool back = t >= 32;
-  const int s = back ? t - 32 : t;
+  const bool back = t >= 64;
+  const int s = back ? t - 64 : t;
   if (s >= nseg) return;
   const int i0 = s * seglen, i1 = min(n, i0 + seglen);
   double g[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   if (!back) {
-#pragma unroll 4
+#pragma unroll 8
     for (int i = i0; i < i1; ++i) {
       const double* W = fac + (int64_t)i * DLR_REC;
       double h[9];
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64) void k_dlr_prefix(const double* __restrict__ fa
       }
     }
   } else {
-#pragma unroll 4
+#pragma unroll 8
     for (int i = i1 - 1; i >= i0; --i) {
       const double* W = fac + (int64_t)(i + 1) * DLR_REC;  // record n is all zero
       double h[9];
@@ -321,11 +321,14 @@ __device__ __forceinline__ DlrCol dlr_col(const DlrColsArgs& A, int col) {
 __global__ __launch_bounds__(256) void k_dlr_fwd(DlrColsArgs A) {
   constexpr int CH = 64;
   __shared__ double fb[CH * DLR_REC];
+  __shared__ double rv[CH * 3];   // the dense right-hand side of the chunk (read by the one lane that owns that column: from
+                                  // global memory its loads sat between that lane's stores, one round trip per pose)
   const int tid = threadIdx.x;
   const int col = blockIdx.x * 256 + tid;
   const int s = blockIdx.y;
   const int i0 = s * A.seglen, i1 = min(A.n, i0 + A.seglen);
   const DlrCol c = dlr_col(A, col);
+  const bool vec_here = A.vec_col >= (int)blockIdx.x * 256 && A.vec_col < (int)blockIdx.x * 256 + 256 && A.vec_col < A.ncols;
   const int64_t ld = A.ld;
   double* __restrict__ X = A.X + col;
   double t0 = 0, t1 = 0, t2 = 0;
@@ -333,6 +336,11 @@ __global__ __launch_bounds__(256) void k_dlr_fwd(DlrColsArgs A) {
     const int cnt = min(CH, i1 - c0);
     __syncthreads();
     for (int idx = tid; idx < cnt * DLR_REC; idx += 256) fb[idx] = A.fac[(int64_t)c0 * DLR_REC + idx];
+    if (vec_here && tid < cnt * 3) {
+      double v = A.rhs_b[3 * (int64_t)c0 + tid];
+      if (A.rhs_sub) v -= A.rhs_sub[3 * (int64_t)c0 + tid];
+      rv[tid] = v;
+    }
     __syncthreads();
 #pragma unroll 4
     for (int ii = 0; ii < cnt; ++ii) {
@@ -340,10 +348,7 @@ __global__ __launch_bounds__(256) void k_dlr_fwd(DlrColsArgs A) {
       double r0 = 0, r1 = 0, r2 = 0;
       if (i == c.a) { r0 = c.ra0; r1 = c.ra1; r2 = c.ra2; }
       if (i == c.b) { r0 += c.rb0; r1 += c.rb1; r2 += c.rb2; }
-      if (c.isvec) {
-        r0 = A.rhs_b[3 * (int64_t)i]; r1 = A.rhs_b[3 * (int64_t)i + 1]; r2 = A.rhs_b[3 * (int64_t)i + 2];
-        if (A.rhs_sub) { r0 -= A.rhs_sub[3 * (int64_t)i]; r1 -= A.rhs_sub[3 * (int64_t)i + 1]; r2 -= A.rhs_sub[3 * (int64_t)i + 2]; }
-      }
+      if (c.isvec) { r0 = rv[3 * ii]; r1 = rv[3 * ii + 1]; r2 = rv[3 * ii + 2]; }
       const double* W = fb + ii * DLR_REC;
       const double n0 = r0 - (W[0] * t0 + W[1] * t1 + W[2] * t2);
       const double n1 = r1 - (W[3] * t0 + W[4] * t1 + W[5] * t2);
@@ -376,16 +381,16 @@ __global__ __launch_bounds__(256) void k_dlr_mid(DlrColsArgs A) {
   double* __restrict__ X = A.X + col;
   // t entering this segment: t_in(q + 1) = E(q) + F_q t_in(q),  F_q = G at the last pose of segment q
   double ti0 = 0, ti1 = 0, ti2 = 0;
-  for (int q0 = 0; q0 < s; q0 += 8) {   // 8 segments' end states requested together (the chain over q is 3 FMAs per step)
-    double ev[8][3];
+  for (int q0 = 0; q0 < s; q0 += 16) {   // 16 segments' end states requested together (the chain over q is 3 FMAs per step)
+    double ev[16][3];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const double* e = A.E + (int64_t)min(q0 + u, s - 1) * 3 * ld + col;
 #pragma unroll
       for (int c = 0; c < 3; ++c) ev[u][c] = act ? e[c * ld] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int q = q0 + u;
       if (q < s) {
         const double* F = A.pre + (int64_t)(min(n, (q + 1) * A.seglen) - 1) * DLR_PRE;
@@ -408,16 +413,16 @@ __global__ __launch_bounds__(256) void k_dlr_mid(DlrColsArgs A) {
       gb[idx] = A.pre[(int64_t)(c0 + ii) * DLR_PRE + (idx - 9 * ii)];
     }
     __syncthreads();
-    for (int b1 = cnt; b1 > 0; b1 -= 8) {   // poses b1-1 .. b1-8 of the chunk, their loads issued together
-      double tl[8][3];
+    for (int b1 = cnt; b1 > 0; b1 -= 16) {   // poses b1-1 .. b1-16 of the chunk, their loads issued together
+      double tl[16][3];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int i = c0 + max(b1 - 1 - u, 0);
 #pragma unroll
         for (int c = 0; c < 3; ++c) tl[u][c] = act ? X[(3 * (int64_t)i + c) * ld] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int ii = b1 - 1 - u;
         if (ii >= 0) {
           const int i = c0 + ii;
@@ -447,25 +452,27 @@ __global__ __launch_bounds__(256) void k_dlr_mid(DlrColsArgs A) {
 }
 
 __global__ __launch_bounds__(256) void k_dlr_fix(DlrColsArgs A) {
+  __shared__ double gbs[64 * 9];
   const int col = blockIdx.x * 256 + threadIdx.x;
   const int s = blockIdx.y;
-  if (s == A.nseg - 1 || col >= A.ncols) return;  // nothing enters the last segment
+  if (s == A.nseg - 1) return;   // nothing enters the last segment (the whole workgroup leaves)
+  const bool live = col < A.ncols;
   const int n = A.n;
   const int i0 = s * A.seglen, i1 = min(n, i0 + A.seglen);
   const int64_t ld = A.ld;
   double* __restrict__ X = A.X + col;
   // x entering this segment from the right: x_in(q - 1) = E2(q) + Fb_q x_in(q),  Fb_q = Gb at the first pose of segment q
   double x0 = 0, x1 = 0, x2 = 0;
-  for (int q0 = A.nseg - 1; q0 > s; q0 -= 8) {   // 8 segments' start states requested together
-    double ev[8][3];
+  for (int q0 = A.nseg - 1; q0 > s; q0 -= 16) {   // 16 segments' start states requested together
+    double ev[16][3];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const double* e = A.E2 + (int64_t)max(q0 - u, s + 1) * 3 * ld + col;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) ev[u][c] = e[c * ld];
+      for (int c = 0; c < 3; ++c) ev[u][c] = live ? e[c * ld] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int q = q0 - u;
       if (q > s) {
         const double* F = A.pre + (int64_t)(q * A.seglen) * DLR_PRE + 9;
@@ -476,23 +483,35 @@ __global__ __launch_bounds__(256) void k_dlr_fix(DlrColsArgs A) {
       }
     }
   }
-  // every pose's update is independent of the others: 8 poses' loads are issued before the first of them is used
-  for (int b0 = i0; b0 < i1; b0 += 8) {
-    double v[8][3];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = min(b0 + u, i1 - 1);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) v[u][c] = X[(3 * (int64_t)i + c) * ld];
+  // every pose's update is independent of the others: 16 poses' loads are issued before the first of them is used; Gb comes
+  // through LDS (read from global memory its loads sat between the stores: one round trip per pose)
+  for (int c0 = i0; c0 < i1; c0 += 64) {
+    const int cnt = min(64, i1 - c0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < cnt * 9; idx += 256) {
+      const int ii = idx / 9;
+      gbs[idx] = A.pre[(int64_t)(c0 + ii) * DLR_PRE + 9 + (idx - 9 * ii)];
     }
+    __syncthreads();
+    if (!live) continue;
+    for (int b0 = 0; b0 < cnt; b0 += 16) {
+      double v[16][3];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = b0 + u;
-      if (i < i1) {
-        const double* G = A.pre + (int64_t)i * DLR_PRE + 9;
-        X[(3 * (int64_t)i) * ld] = v[u][0] + (G[0] * x0 + G[1] * x1 + G[2] * x2);
-        X[(3 * (int64_t)i + 1) * ld] = v[u][1] + (G[3] * x0 + G[4] * x1 + G[5] * x2);
-        X[(3 * (int64_t)i + 2) * ld] = v[u][2] + (G[6] * x0 + G[7] * x1 + G[8] * x2);
+      for (int u = 0; u < 16; ++u) {
+        const int i = c0 + min(b0 + u, cnt - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[u][c] = X[(3 * (int64_t)i + c) * ld];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int ii = b0 + u;
+        if (ii < cnt) {
+          const int i = c0 + ii;
+          const double* G = gbs + ii * 9;
+          X[(3 * (int64_t)i) * ld] = v[u][0] + (G[0] * x0 + G[1] * x1 + G[2] * x2);
+          X[(3 * (int64_t)i + 1) * ld] = v[u][1] + (G[3] * x0 + G[4] * x1 + G[5] * x2);
+          X[(3 * (int64_t)i + 2) * ld] = v[u][2] + (G[6] * x0 + G[7] * x1 + G[8] * x2);
+        }
       }
     }
   }

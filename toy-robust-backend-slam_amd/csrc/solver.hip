@@ -1057,7 +1057,9 @@ int pgo_handle::direct_setup(int32_t N) {
   PGOC(dalloc(&dl_nm, (int64_t)dl_Kp * dl_Kp));
   PGOC(dalloc(&dl_cy, dl_Kp));
   PGOC(dalloc(&dl_pre, (int64_t)dev::DLR_PRE * N));
-  dl_seglen = std::max(1, (N + dev::DLR_MAX_SEG - 1) / dev::DLR_MAX_SEG);
+  int want_seg = 32;   // segments the chain sweeps are cut into (PGO_DIRECT_NSEG: experiments, <= 64)
+  if (const char* ns = getenv("PGO_DIRECT_NSEG")) want_seg = std::min(dev::DLR_MAX_SEG, std::max(1, atoi(ns)));
+  dl_seglen = std::max(1, (N + want_seg - 1) / want_seg);
   dl_nseg = (N + dl_seglen - 1) / dl_seglen;
   PGOC(dalloc(&dl_E, (int64_t)dl_nseg * 3 * dl_ld));
   PGOC(dalloc(&dl_E2, (int64_t)dl_nseg * 3 * dl_ld));
@@ -1104,7 +1106,7 @@ int pgo_handle::direct_solve() {
   PGOC(check_launch("k_dlr_setup"));
   hipLaunchKernelGGL(dev::k_dlr_factor, dim3(dl_nsep + 1), dim3(64), 0, stream, (const double*)dl_trec, n, dl_fac, A);
   PGOC(check_launch("k_dlr_factor"));
-  hipLaunchKernelGGL(dev::k_dlr_prefix, dim3(1), dim3(64), 0, stream, (const double*)dl_fac, n, dl_nseg, dl_seglen, dl_pre);
+  hipLaunchKernelGGL(dev::k_dlr_prefix, dim3(1), dim3(128), 0, stream, (const double*)dl_fac, n, dl_nseg, dl_seglen, dl_pre);
   PGOC(check_launch("k_dlr_prefix"));
   dev::DlrColsArgs C;
   C.fac = dl_fac;
