@@ -389,8 +389,21 @@ def main():
                         wl["INTEL+50 METHOD %d (%s)" % (m, label)] = {
                             "gn_it_per_s": sm.iterations / sm.seconds_total, "iterations": sm.iterations, "pcg_iters": sm.total_pcg_iters,
                             "final_cost": sm.final_cost, "max_dxy_vs_oracle_direct_solve": float(np.abs(px[:, :2] - ref[:, :2]).max())}
+                # BASELINE configs[2]: M3500 / MIT, DCS on / off (library defaults: MIT takes the direct solve, M3500 -- 1954 edges
+                # outside its odometry chain -- PCG with dense 32-pose blocks)
+                for name in ("MIT", "M3500"):
+                    gd = P.ReadG2O(os.path.join(data, name + ".g2o"))
+                    for m in (1, 0):
+                        sv = P.Solver(gd, P.Options(method=m, pcg_max_iters=400000), device=local_rank)
+                        solver = "direct" if sv.info().linear_solver == 2 else "PCG rtol 1e-10"
+                        sv.close()
+                        sm, px = run(gd, method=m, pcg_max_iters=400000)
+                        ref = np.load(os.path.join(golden, "lm_%s_out0_m%d_poses.npy" % (name, m)))
+                        wl["%s METHOD %d (exact: %s)" % (name, m, solver)] = {
+                            "gn_it_per_s": sm.iterations / sm.seconds_total, "iterations": sm.iterations, "pcg_iters": sm.total_pcg_iters,
+                            "final_cost": sm.final_cost, "max_dxy_vs_oracle_direct_solve": float(np.abs(px[:, :2] - ref[:, :2]).max())}
             except Exception as e:  # the datasets are test fixtures: report, do not fail the bench line
-                wl["INTEL+50"] = {"error": repr(e)}
+                wl["datasets"] = {"error": repr(e)}
             for n in (10000, 100000):
                 gs_ = P.synth_manhattan(n, 4.0, 0.10, 20260410)
                 sm, _ = run(gs_, method=1, max_iters=50, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0, pcg_rtol=args.pcg_rtol,

@@ -1503,12 +1503,16 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
     h_scal[2] = h_solo->step2;
   } else {
     PGOC(reduce_to_scal({{part[1], g_flat, 0}, {part[0], g_flat, 0}, {part[3], g_flat, 0}, {part[5], g_flat, 0}}, 0));
-    PGOC(fetch_scal(0, direct ? 10 : 4));
+    // the candidate's cost is evaluated in the same breath (scal[6..7]; wasted only when the step turns out invalid): one
+    // host synchronisation for the model terms AND the candidate instead of two
+    PGOC(allgather(cand));
+    PGOC(eval_enqueue(cand, sw_cand, 1, false, 6));
+    PGOC(fetch_scal(0, has_sw ? 15 : 10));
     h_scal[1] = h_scal[0] - h_scal[1] - h_scal[3];   // y.(H y)
     if (direct) R.pcg_rel_residual = dl_rel = (h_scal[9] > 0.0) ? std::sqrt(h_scal[8] / h_scal[9]) : 0.0;
   }
   if (has_sw) {
-    PGOC(fetch_scal(13, 2));
+    if (solo) PGOC(fetch_scal(13, 2));
     model_sw = h_scal[13];
     step2_sw = h_scal[14];
   }
@@ -1536,12 +1540,14 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
   }
   invalid_run = 0;
   t0 = wall_s();
-  PGOC(allgather(cand));
-  PGOC(eval_enqueue(cand, sw_cand, 1, false, 0));
-  PGOC(fetch_scal(0, 2));
+  if (solo) {   // (the one-workgroup solve synchronised inside pcg(): its candidate is evaluated here)
+    PGOC(allgather(cand));
+    PGOC(eval_enqueue(cand, sw_cand, 1, false, 6));
+    PGOC(fetch_scal(6, 2));
+  }
   t_cand += wall_s() - t0;
-  double cand_cost = h_scal[0];
-  if (h_scal[1] > 0.0 || !std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+  double cand_cost = h_scal[6];
+  if (h_scal[7] > 0.0 || !std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
   R.step_norm = std::sqrt(step2);
   R.cost_change = cost - cand_cost;
   R.gradient_max_norm = gmax;
@@ -1570,25 +1576,40 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
     hipLaunchKernelGGL(dev::k_xnorm, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, poses, scale, part[1]);
     PGOC(check_launch("k_xnorm"));
     PGOC(reduce_to_scal({{part[1], g_flat, 0}}, 3));
-    int st_lin = linearize(false, !has_sw);  // METHOD 2 assembles in refresh_switch_system(), with the new radius
-    if (st_lin == PGO_ERR_NUMERIC) {
-      finish(PGO_TERM_FAILURE);
-      return PGO_OK;
-    }
-    PGOC(st_lin);
-    cost = h_scal[0];
     const double t = 2.0 * rho - 1.0;
-    radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
-    radius = std::min(opt.max_radius, radius);
     if (has_sw) {
+      int st_lin = linearize(false, false);  // METHOD 2 assembles in refresh_switch_system(), with the new radius
+      if (st_lin == PGO_ERR_NUMERIC) {
+        finish(PGO_TERM_FAILURE);
+        return PGO_OK;
+      }
+      PGOC(st_lin);
+      cost = h_scal[0];
+      radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+      radius = std::min(opt.max_radius, radius);
       PGOC(fetch_scal(3, 1));
       xnorm2_pose = h_scal[3];
       PGOC(refresh_switch_system());  // gmax over poses and switches, x_norm, reduced system for the next iteration
     } else {
+      // K1, K2 and the gradient norm are enqueued together and fetched with ONE host synchronisation (three before: a
+      // synchronisation is ~25 us of idle GPU, 4 % of an LM iteration on INTEL); if K1 reports a non-finite value the
+      // assembled system is discarded with the step, as before
+      const double tl0 = wall_s();
+      PGOC(eval_enqueue(poses, sw, 1, true, 0));
+      PGOC(assemble_enqueue());
       hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
       PGOC(check_launch("k_grad_max"));
       PGOC(reduce_to_scal({{part[0], g_flat, 1}}, 2, true));
-      PGOC(fetch_scal(2, 2));
+      PGOC(fetch_scal(0, 4));
+      t_eval += wall_s() - tl0;  // (K2 and the norms included: no host synchronisation separates them any more)
+      if (h_scal[1] > 0.0 || !std::isfinite(h_scal[0])) {
+        (void)fail(PGO_ERR_NUMERIC, "residual/Jacobian evaluation produced non-finite values");
+        finish(PGO_TERM_FAILURE);
+        return PGO_OK;
+      }
+      cost = h_scal[0];
+      radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+      radius = std::min(opt.max_radius, radius);
       gmax = h_scal[2];
       xnorm2_pose = h_scal[3];
       x_norm = std::sqrt(xnorm2_pose);
