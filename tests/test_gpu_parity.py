@@ -275,7 +275,9 @@ def test_direct_solve_eligibility(pgo):
     assert pgo.Solver(gi, pgo.Options(method=1)).info().linear_solver == 2
     assert pgo.Solver(gi, pgo.Options(method=1, pcg_rtol=0.1)).info().linear_solver == 1          # inexact steps were asked for
     assert pgo.Solver(gi, pgo.Options(method=1, pcg_chain_len=64)).info().linear_solver == 1      # the caller chose a preconditioner
-    assert pgo.Solver(gi, pgo.Options(method=2)).info().linear_solver == 1                        # switches: PCG
+    assert pgo.Solver(gi, pgo.Options(method=2)).info().linear_solver == 2                        # switches are eliminated per edge first
+    with pytest.raises(pgo.PgoError):                                                              # ill-conditioned chain blocks: PCG only
+        pgo.Solver(pgo.ReadG2O(os.path.join(DATA, "INTEL.g2o")), pgo.Options(method=1, info_weighting=1, linear_solver=2))
     for name in ("M3500", "FRH"):                             # many edges outside the chain: auto stays with PCG, forcing works
         g = load(pgo, name)
         assert pgo.Solver(g, pgo.Options(method=1)).info().linear_solver == 1
@@ -685,8 +687,9 @@ def test_switchable_edge_kernel_parity(pgo, oracle, name, n_out):
     s.close(); s0.close()
 
 
+@pytest.mark.parametrize("solver", [0, 1])
 @pytest.mark.parametrize("name,n_out", [("INTEL", 50), ("M3500", 0), ("MIT", 0)])
-def test_switchable_lm_matches_golden(pgo, name, n_out):
+def test_switchable_lm_matches_golden(pgo, name, n_out, solver):
     """full 50-iteration LM on the joint (poses, switches) problem: the GPU eliminates every switch exactly (per-edge Schur
     complement) and must reproduce the oracle's joint sparse direct solve -- poses, switches, LM history"""
     tag = "%s_out%d_m2" % (name, n_out)
@@ -694,7 +697,10 @@ def test_switchable_lm_matches_golden(pgo, name, n_out):
     ref = np.load(os.path.join(GOLDEN, "lm_%s_poses.npy" % tag))
     ref_sw = np.load(os.path.join(GOLDEN, "lm_%s_switches.npy" % tag))
     g = load(pgo, name, n_out)
-    s = pgo.Solver(g, pgo.Options(method=2, pcg_max_iters=200000))
+    if solver == 0 and name not in DIRECT_OK:
+        pytest.skip("auto = PCG on this dataset: covered by solver = 1")
+    s = pgo.Solver(g, pgo.Options(method=2, pcg_max_iters=200000, linear_solver=solver))
+    assert s.info().linear_solver == (2 if solver == 0 else 1)
     summ = s.solve()
     x, sw = s.poses(), s.switches()
     assert summ.termination == fx["termination"] and summ.iterations == fx["iterations"]

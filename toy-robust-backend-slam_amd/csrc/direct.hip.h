@@ -57,22 +57,45 @@ struct DlrArgs {
   int32_t nsep;
   int32_t sep[DLR_MAX_SEP];
   double* ksep;               // [nsep][18]: the couplings taken out of T: C_s = T[s][s-1] (9) | C_{s+1} = T[s+1][s] (9)
+  // METHOD 2 (switches eliminated per edge, k_assemble<true>): d e / d s per edge and the elimination coefficient c; null otherwise
+  const double* sw_js;
+  const double* sw_c;
+  int32_t rec_n;              // doubles per edge record (REC, or REC_INFO in the information-weighted mode)
+  int32_t rec_info;           // 1: information-weighted records (the last column of d e / d P2 is stored: b3)
 };
 
-// scaled Jacobian blocks of edge e (record layout: kernels.hip.h REC; the second block is implied)
-__device__ __forceinline__ void dlr_blocks(const double* __restrict__ jr, int64_t e, const double* __restrict__ sa,
-                                           const double* __restrict__ sb, double (&Xa)[9], double (&Xb)[9]) {
-  const double* R = jr + e * REC;
+// scaled Jacobian blocks of edge e (record layouts: kernels.hip.h REC / REC_INFO; the second block is implied up to its
+// last column).  METHOD 2: the edge's switch has been eliminated, its term of the pose system is X'(I - c j j')X
+// (k_assemble<true>); with beta = (sqrt(1 - c |j|^2) - 1) / |j|^2 the factor (I + beta j j') X has exactly that Gram
+// matrix (c |j|^2 < 1 by construction), so the edge stays ONE positive semi-definite low-rank term.
+__device__ __forceinline__ void dlr_blocks(const DlrArgs& A, int64_t e, const double* __restrict__ sa, const double* __restrict__ sb,
+                                           double (&Xa)[9], double (&Xb)[9]) {
+  const double* R = A.jr + e * A.rec_n;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const double a0 = R[3 * k], a1 = R[3 * k + 1], a2 = R[3 * k + 2];
-    const double b2 = (k == 2) ? R[9] : 0.0;
+    const double b2 = A.rec_info ? R[9 + k] : ((k == 2) ? R[9] : 0.0);
     Xa[3 * k] = a0 * sa[0];
     Xa[3 * k + 1] = a1 * sa[1];
     Xa[3 * k + 2] = a2 * sa[2];
     Xb[3 * k] = -a0 * sb[0];
     Xb[3 * k + 1] = -a1 * sb[1];
     Xb[3 * k + 2] = b2 * sb[2];
+  }
+  if (A.sw_c != nullptr) {
+    const double cc = A.sw_c[e];
+    if (cc != 0.0) {
+      const double j0 = A.sw_js[3 * e], j1 = A.sw_js[3 * e + 1], j2 = A.sw_js[3 * e + 2];
+      const double jj = j0 * j0 + j1 * j1 + j2 * j2;
+      const double beta = jj > 0.0 ? (sqrt(fmax(0.0, 1.0 - cc * jj)) - 1.0) / jj : 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double da = beta * (j0 * Xa[c] + j1 * Xa[3 + c] + j2 * Xa[6 + c]);
+        const double db = beta * (j0 * Xb[c] + j1 * Xb[3 + c] + j2 * Xb[6 + c]);
+        Xa[c] += da * j0; Xa[3 + c] += da * j1; Xa[6 + c] += da * j2;
+        Xb[c] += db * j0; Xb[3 + c] += db * j1; Xb[6 + c] += db * j2;
+      }
+    }
   }
 }
 
@@ -88,7 +111,7 @@ __global__ void k_dlr_setup(DlrArgs A) {
       if (e < 0) continue;
       const int a = A.e_ia[e], b = A.e_ib[e];
       double Xa[9], Xb[9];
-      dlr_blocks(A.jr, e, A.scale + 3 * (int64_t)a, A.scale + 3 * (int64_t)b, Xa, Xb);
+      dlr_blocks(A, e, A.scale + 3 * (int64_t)a, A.scale + 3 * (int64_t)b, Xa, Xb);
       const bool self_is_a = (a == i);
       double Xi[9], Xo[9];
 #pragma unroll
@@ -131,7 +154,7 @@ __global__ void k_dlr_setup(DlrArgs A) {
     const int e = A.lr_edge[j];
     const int a = A.e_ia[e], b = A.e_ib[e];
     double Xa[9], Xb[9];
-    dlr_blocks(A.jr, e, A.scale + 3 * (int64_t)a, A.scale + 3 * (int64_t)b, Xa, Xb);
+    dlr_blocks(A, e, A.scale + 3 * (int64_t)a, A.scale + 3 * (int64_t)b, Xa, Xb);
     double* o = A.vrec + (int64_t)j * DLR_V;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {

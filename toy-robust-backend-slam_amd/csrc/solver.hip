@@ -1003,7 +1003,10 @@ int pgo_handle::direct_setup(int32_t N) {
   if (want == 0 && (!(opt.pcg_rtol <= 1e-8) || opt.pcg_chain_len != -1 || opt.pcg_block_poses != 0)) return PGO_OK;
   if (world != 1 || force_collectives) return no("one rank only");
   if (batch_mode) return no("not inside a batched handle");
-  if (has_sw || info_mode) return no("METHOD 0 / 1 without information weighting only");
+  // information weighting: the chain blocks inherit the information matrices' condition numbers (INTEL: 1e11) and the
+  // Woodbury correction loses the solution (measured: residual 1e-3 after refinement); MIT-like inputs would work, but the
+  // library cannot tell from the graph -- PCG there
+  if (info_mode) return no("not with information weighting");
   if (fixed_internal < 0) return no("needs a constant pose (it anchors the chain)");
   if (!perm.empty()) return no("the internal pose ordering is on");
   if (N < 2 || N > DIRECT_MAX_POSES) return no("2 .. " + std::to_string(DIRECT_MAX_POSES) + " poses");
@@ -1102,6 +1105,10 @@ int pgo_handle::direct_solve() {
   A.nsep = dl_nsep;
   for (int j = 0; j < dev::DLR_MAX_SEP; ++j) A.sep[j] = dl_sep[j];
   A.ksep = dl_ksep;
+  A.sw_js = has_sw ? sw_js : nullptr;
+  A.sw_c = has_sw ? sw_c : nullptr;
+  A.rec_n = rec_doubles;
+  A.rec_info = info_mode ? 1 : 0;
   hipLaunchKernelGGL(dev::k_dlr_setup, dim3((n + dl_m + 255) / 256), dim3(256), 0, stream, A);
   PGOC(check_launch("k_dlr_setup"));
   hipLaunchKernelGGL(dev::k_dlr_factor, dim3(dl_nsep + 1), dim3(64), 0, stream, (const double*)dl_trec, n, dl_fac, A);
