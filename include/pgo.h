@@ -185,7 +185,7 @@ typedef struct pgo_options {
                                       exactly) + every other edge as a low-rank term through the Woodbury identity -- a dense
                                       Cholesky of order 3 x (edges outside the chain) -- + iterative refinement.  One rank, no
                                       information weighting, a constant pose, every consecutive pose pair joined by an edge, at most 2047
-                                      edges outside the chain, at most 16384 poses; else PGO_ERR_UNSUPPORTED;
+                                      edges outside the chain, at most 65536 poses; else PGO_ERR_UNSUPPORTED;
                                   0 (default) = auto: 2 where it applies with at most 682 edges outside the chain (INTEL, MIT,
                                       CSAIL, FR079 ...) when pcg_rtol <= 1e-8 (the "exact" mode) and pcg_block_poses /
                                       pcg_chain_len are left at auto; else 1                                               */

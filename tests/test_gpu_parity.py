@@ -268,6 +268,27 @@ def test_direct_solve_agrees_with_pcg(pgo, name, n_out, method):
     assert d < 1e-7 and out[2][2].total_pcg_iters == 0
 
 
+@pytest.mark.parametrize("n_poses,epp", [(5000, 1.012), (12001, 1.004), (40001, 1.0012)])
+def test_direct_solve_long_chain(pgo, n_poses, epp):
+    """a long odometry chain with a few dozen loop closures: chain sweeps with segments of several LDS chunks (INTEL's
+    segments fit one), factorisation pieces of thousands of poses -- direct solve against PCG to 1e-12"""
+    g = pgo.synth_manhattan(n_poses, epp, 0.10, 77)
+    out = {}
+    for ls in (2, 1):
+        s = pgo.Solver(g, pgo.Options(method=1, max_iters=5, linear_solver=ls, pcg_rtol=1e-12, pcg_max_iters=400000))
+        sm = s.solve()
+        out[ls] = (s.iter_records(), s.poses(), sm, s.info().direct_rank)
+        s.close()
+    assert 0 < out[2][3] <= 2048
+    for a, b in zip(out[2][0], out[1][0]):
+        assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-8)
+        assert a["iter"] == 0 or a["pcg_rel_residual"] < 1e-8
+    d = np.abs(out[2][1] - out[1][1]).max()
+    print(f"{n_poses} poses, {g.n_edges - (n_poses - 1)} edges outside the chain (rank {out[2][3]}): direct vs PCG max |d pose| {d:.2e}; "
+          f"{out[2][2].iterations / out[2][2].seconds_total:.0f} vs {out[1][2].iterations / out[1][2].seconds_total:.0f} GN it/s")
+    assert d < 1e-6
+
+
 def test_direct_solve_eligibility(pgo):
     """auto picks the direct solve only in the exact mode on chain-like graphs; forcing it elsewhere is an error, not a
     silent fallback"""

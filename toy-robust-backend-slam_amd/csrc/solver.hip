@@ -984,7 +984,7 @@ int pgo_handle::lm_begin() {
 // SPARSE_NORMAL_CHOLESKY, main.cpp:154-163) and only while the caller left the preconditioner to the library; it needs
 // one rank, METHOD 0 / 1, a constant pose, an edge between every pair of consecutive poses, and few enough other edges.
 namespace {
-constexpr int DIRECT_MAX_POSES = 16384;
+constexpr int DIRECT_MAX_POSES = 65536;
 constexpr int DIRECT_MAX_RANK = 6144;   // 3 x (edges outside the chain) + 1: order of the dense capacitance matrix
 constexpr int DIRECT_AUTO_RANK = 2048;  // auto takes the direct solve up to this rank (INTEL + 50: 918 -> 1.5 ms per LM iteration; FRH, 4515: 13 ms
                                         // against 29 ms of PCG, but one refinement step leaves 5e-8 there; M3500, 5862: 22 ms, the same as PCG)
