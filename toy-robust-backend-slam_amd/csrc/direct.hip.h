@@ -29,7 +29,7 @@ constexpr int DLR_REC = 16;  // doubles per pose: input record M (6: 00 01 02 11
                              // factor record W (9, row-major) | S^-1 (6) | pad
 constexpr int DLR_V = 18;    // doubles per low-rank edge: Xa (9) | Xb (9), X[k][c] = d e_k / d (pose)_c * scale_c
 constexpr int CHOL_NB = 32;
-constexpr int DLR_MAX_SEP = 3;   // separator poses: the chain factorisation runs nsep + 1 = 4 pieces side by side
+constexpr int DLR_MAX_SEP = 15;  // separator poses: the chain factorisation runs nsep + 1 pieces side by side (3 separators up to ~2000 poses)
 
 struct DlrArgs {
   int32_t n;                  // poses
@@ -564,10 +564,10 @@ struct DlrSepArgs {
   double* Wm;           // [nU][ld]
 };
 
-__global__ __launch_bounds__(64) void k_dlr_sep_system(DlrSepArgs A) {
+__global__ __launch_bounds__(256) void k_dlr_sep_system(DlrSepArgs A) {
   __shared__ double Ab[DLR_MAX_U * 2 * DLR_MAX_U];   // [S | I], row stride 2 nU
   const int tid = threadIdx.x, nU = A.nU, w2 = 2 * nU;
-  for (int e = tid; e < nU * nU; e += 64) {
+  for (int e = tid; e < nU * nU; e += 256) {
     const int u = e / nU, v = e - u * nU;
     const int j = u / 3, c = u - 3 * j, jv = v / 3, cv = v - 3 * jv;
     const int sp = A.sep[j];
@@ -587,19 +587,19 @@ __global__ __launch_bounds__(64) void k_dlr_sep_system(DlrSepArgs A) {
   __syncthreads();
   for (int k = 0; k < nU; ++k) {   // Gauss-Jordan, no pivoting (SPD)
     const double pinv = 1.0 / Ab[k * w2 + k];
-    double nv[6];
+    double nv[16];
     int cnt = 0;
-    for (int e = tid; e < nU * w2; e += 64, ++cnt) {
+    for (int e = tid; e < nU * w2; e += 256, ++cnt) {
       const int r = e / w2, c = e - r * w2;
       const double pk = Ab[k * w2 + c] * pinv;
       nv[cnt] = (r == k) ? pk : Ab[e] - Ab[r * w2 + k] * pk;
     }
     __syncthreads();
     cnt = 0;
-    for (int e = tid; e < nU * w2; e += 64, ++cnt) Ab[e] = nv[cnt];
+    for (int e = tid; e < nU * w2; e += 256, ++cnt) Ab[e] = nv[cnt];
     __syncthreads();
   }
-  for (int e = tid; e < nU * nU; e += 64) A.Sinv[e] = Ab[(e / nU) * w2 + nU + (e % nU)];
+  for (int e = tid; e < nU * nU; e += 256) A.Sinv[e] = Ab[(e / nU) * w2 + nU + (e % nU)];
 }
 
 // w_j = S^-1 (Ms z_s - C_s z_{s-1} - C_{s+1}' z_{s+1}) for the columns j < ncols of X

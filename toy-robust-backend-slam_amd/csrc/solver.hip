@@ -177,7 +177,7 @@ struct pgo_handle {
   double *dl_trec = nullptr, *dl_fac = nullptr, *dl_pre = nullptr, *dl_vrec = nullptr, *dl_Z = nullptr, *dl_cap = nullptr, *dl_dwork = nullptr,
          *dl_nm = nullptr, *dl_cy = nullptr, *dl_cvec = nullptr, *dl_x1 = nullptr, *dl_E = nullptr, *dl_E2 = nullptr;
   int dl_nseg = 1, dl_seglen = 1;
-  int dl_nsep = 0, dl_sep[dev::DLR_MAX_SEP] = {0, 0, 0}, dl_nU = 0;
+  int dl_nsep = 0, dl_sep[dev::DLR_MAX_SEP] = {0}, dl_nU = 0;
   double *dl_ksep = nullptr, *dl_R = nullptr, *dl_Wm = nullptr;
   double dl_rel = 0.0;  // |g - (H + D'D) y| / |g| of the latest direct solve
 
@@ -1035,7 +1035,7 @@ int pgo_handle::direct_setup(int32_t N) {
   {
     const char* se = getenv("PGO_DIRECT_SEP");
     if (N >= 256 && !(se && se[0] == '0')) {
-      dl_nsep = dev::DLR_MAX_SEP;
+      dl_nsep = std::min(dev::DLR_MAX_SEP, std::max(3, (int)(N / 400) - 1));   // pieces of ~300-400 poses, at least 4 of them
       for (int j = 0; j < dl_nsep; ++j) dl_sep[j] = (int)(((int64_t)(j + 1) * N) / (dl_nsep + 1));
     }
   }
@@ -1171,7 +1171,7 @@ int pgo_handle::direct_solve() {
     SA.X = dl_Z;
     SA.ld = dl_ld;
     SA.ncols = K + 1;
-    hipLaunchKernelGGL(dev::k_dlr_sep_system, dim3(1), dim3(64), 0, stream, SA);
+    hipLaunchKernelGGL(dev::k_dlr_sep_system, dim3(1), dim3(256), 0, stream, SA);
     PGOC(check_launch("k_dlr_sep_system"));
   }
   PGOC(separator_fix(dl_Z, dl_ld, K + 1));
