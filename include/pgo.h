@@ -340,7 +340,7 @@ typedef struct pgo_handle_info {
   int32_t pcg_graph_replay;          /* 1 = the PCG slices are replayed from a captured hipGraph                    */
   int32_t linear_solver;             /* resolved: 1 = PCG, 2 = direct (chain + low rank)                            */
   int32_t direct_rank;               /* order of the direct solve's dense capacitance matrix (3 x edges outside the chain) */
-  int32_t _pad;
+  int32_t direct_fallbacks;          /* LM iterations whose direct solve gave no usable step and were redone by PCG  */
 } pgo_handle_info;
 int pgo_get_info(const pgo_t* h, pgo_handle_info* out);                           /* [host] */
 

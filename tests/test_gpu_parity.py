@@ -289,6 +289,24 @@ def test_direct_solve_long_chain(pgo, n_poses, epp):
     assert d < 1e-6
 
 
+def test_direct_solve_failure_falls_back_to_pcg(pgo, monkeypatch):
+    """a direct solve that yields no usable step (here: poisoned with NaNs at LM iteration 3 through the test hook) is redone
+    by PCG inside the same LM iteration: the trajectory still reaches the golden fixture"""
+    tag = "INTEL_out50_m1"
+    fx = json.load(open(os.path.join(GOLDEN, "lm_%s.json" % tag)))
+    ref = np.load(os.path.join(GOLDEN, "lm_%s_poses.npy" % tag))
+    monkeypatch.setenv("PGO_DIRECT_FAIL_AT", "3")
+    s = pgo.Solver(load(pgo, "INTEL", 50), pgo.Options(method=1))
+    monkeypatch.delenv("PGO_DIRECT_FAIL_AT")
+    summ = s.solve()
+    recs = s.iter_records()
+    assert s.info().linear_solver == 2 and s.info().direct_fallbacks == 1
+    assert recs[3]["pcg_iters"] > 0 and all(r["pcg_iters"] == 0 for k, r in enumerate(recs) if k != 3)
+    assert [r["step_ok"] for r in recs] == [r["step_ok"] for r in fx["records"]]
+    assert summ.final_cost == pytest.approx(fx["final_cost"], rel=1e-7) and np.abs(s.poses()[:, :2] - ref[:, :2]).max() < 5e-6
+    s.close()
+
+
 def test_direct_solve_eligibility(pgo):
     """auto picks the direct solve only in the exact mode on chain-like graphs; forcing it elsewhere is an error, not a
     silent fallback"""

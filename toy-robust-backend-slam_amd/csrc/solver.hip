@@ -180,6 +180,9 @@ struct pgo_handle {
   int dl_nsep = 0, dl_sep[dev::DLR_MAX_SEP] = {0}, dl_nU = 0;
   double *dl_ksep = nullptr, *dl_R = nullptr, *dl_Wm = nullptr;
   double dl_rel = 0.0;  // |g - (H + D'D) y| / |g| of the latest direct solve
+  bool dl_retry = false;   // the current LM iteration is being redone by PCG after a failed direct solve
+  int dl_fallbacks = 0;    // how often that happened
+  int dl_fail_at = 0;      // PGO_DIRECT_FAIL_AT (tests): poison the direct solve of this LM iteration
 
   // LM state (TrustRegionMinimizer)
   bool lm_active = false, lin_valid = false, lm_done = false;
@@ -525,6 +528,7 @@ struct pgo_handle {
   int pcg(int* iters, double* rel);
   int direct_setup(int32_t N);
   int direct_solve();
+  int factor_chain();
   void fill_summary(pgo_summary* s) const;
 };
 
@@ -1042,6 +1046,7 @@ int pgo_handle::direct_setup(int32_t N) {
   dl_nU = 3 * dl_nsep;
   dl_ld = ((dl_K + 1 + dl_nU + 63) / 64) * 64;
   if (const char* re = getenv("PGO_DIRECT_REFINE")) dl_refine = std::max(0, atoi(re));
+  if (const char* fa = getenv("PGO_DIRECT_FAIL_AT")) dl_fail_at = atoi(fa);
   PGOC(dalloc(&dl_chain_edge, N));
   PGOC(dalloc(&dl_lr_edge, std::max(1, dl_m)));
   PGOC(dalloc(&dl_va, std::max(1, dl_m)));
@@ -1220,6 +1225,8 @@ int pgo_handle::direct_solve() {
   hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)r, (const double*)r, part[2]);
   hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)gs, (const double*)gs, part[4]);
   PGOC(check_launch("k_dot"));
+  if (dl_fail_at > 0 && iter == dl_fail_at)   // test hook (PGO_DIRECT_FAIL_AT): a direct solve that returns NaNs
+    HIPC(hipMemsetAsync(y, 0xFF, (size_t)3 * n * sizeof(double), stream));
   return reduce_to_scal({{part[2], g_flat, 0}, {part[4], g_flat, 0}}, 8);
 }
 
@@ -1441,6 +1448,18 @@ int pgo_handle::lm_iteration(bool* stop) {
   return lm_iteration_tail(stop, R, it0, t0, k_it, rel);
 }
 
+// block LDL' of the chain preconditioner's segments (the records are complete: C part from k_assemble, M part from k_prepare)
+int pgo_handle::factor_chain() {
+  const int n_seg = (S.n_loc + chain_len - 1) / chain_len;
+  if ((chain_chunk ? chain_chunk : dev::CHAIN_CHUNK) == 2)
+    hipLaunchKernelGGL(dev::k_chain_factor<2>, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
+                       chain_len, chain_w, chain_s);
+  else
+    hipLaunchKernelGGL(dev::k_chain_factor<4>, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
+                       chain_len, chain_w, chain_s);
+  return check_launch("k_chain_factor");
+}
+
 // LM diagonal for the current radius (per problem in a batched handle) + the preconditioner's set-up
 int pgo_handle::prepare_system() {
   hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, (const double*)diag_full, S.n_loc, S.lo, fixed_internal, radius,
@@ -1463,16 +1482,7 @@ int pgo_handle::prepare_system() {
     hipLaunchKernelGGL(dev::k_prepare_groups, dim3(grp_prep_grid), dim3(dev::WG), grp_lds, stream, GA);
     PGOC(check_launch("k_prepare_groups"));
   }
-  if (chain_len && !direct) {   // (the records are complete: C part from k_assemble, M part from k_prepare)
-    const int n_seg = (S.n_loc + chain_len - 1) / chain_len;
-    if ((chain_chunk ? chain_chunk : dev::CHAIN_CHUNK) == 2)
-      hipLaunchKernelGGL(dev::k_chain_factor<2>, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
-                         chain_len, chain_w, chain_s);
-    else
-      hipLaunchKernelGGL(dev::k_chain_factor<4>, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
-                         chain_len, chain_w, chain_s);
-    PGOC(check_launch("k_chain_factor"));
-  }
+  if (chain_len && !direct) PGOC(factor_chain());   // (the direct solve does not need the preconditioner; its PCG fallback factorises then)
   return PGO_OK;
 }
 
@@ -1516,7 +1526,7 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
     PGOC(eval_enqueue(cand, sw_cand, 1, false, 6));
     PGOC(fetch_scal(0, has_sw ? 15 : 10));
     h_scal[1] = h_scal[0] - h_scal[1] - h_scal[3];   // y.(H y)
-    if (direct) R.pcg_rel_residual = dl_rel = (h_scal[9] > 0.0) ? std::sqrt(h_scal[8] / h_scal[9]) : 0.0;
+    if (direct && !dl_retry) R.pcg_rel_residual = dl_rel = (h_scal[9] > 0.0) ? std::sqrt(h_scal[8] / h_scal[9]) : 0.0;
   }
   if (has_sw) {
     if (solo) PGOC(fetch_scal(13, 2));
@@ -1527,6 +1537,19 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
   const double ydotg = h_scal[0], yHy = h_scal[1], step2 = h_scal[2] + step2_sw;
   const double model = ydotg - 0.5 * yHy + model_sw;
   if (!std::isfinite(model) || !std::isfinite(step2) || !(model > 0.0)) {  // invalid step
+    if (direct && !dl_retry) {
+      // the direct solve produced no usable step (a capacitance matrix that lost positive definiteness to rounding, a
+      // residual the refinement could not repair): this LM iteration is redone by PCG before Ceres' invalid-step rule applies
+      dl_retry = true;
+      ++dl_fallbacks;
+      int k2 = 0;
+      double rel2 = 0.0;
+      int st2 = chain_len ? factor_chain() : PGO_OK;
+      if (st2 == PGO_OK) st2 = pcg(&k2, &rel2);
+      if (st2 == PGO_OK) st2 = lm_iteration_tail(stop, R, it0, t0, k2, rel2);
+      dl_retry = false;
+      return st2;
+    }
     if (++invalid_run >= 5) {
       termination = PGO_TERM_FAILURE;
       *stop = true;
@@ -1995,6 +2018,7 @@ int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   out->pcg_graph_replay = (h->cg_graph_exec != nullptr && !h->graph_failed) ? 1 : 0;
   out->linear_solver = h->direct ? 2 : 1;
   out->direct_rank = h->direct ? h->dl_K : 0;
+  out->direct_fallbacks = h->dl_fallbacks;
   return PGO_OK;
 }
 
