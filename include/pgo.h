@@ -186,9 +186,11 @@ typedef struct pgo_options {
                                       Cholesky of order 3 x (edges outside the chain) -- + iterative refinement.  One rank, no
                                       information weighting, a constant pose, every consecutive pose pair joined by an edge, at most 2047
                                       edges outside the chain, at most 65536 poses; else PGO_ERR_UNSUPPORTED;
-                                  0 (default) = auto: 2 where it applies with at most 682 edges outside the chain (INTEL, MIT,
-                                      CSAIL, FR079 ...) when pcg_rtol <= 1e-8 (the "exact" mode) and pcg_block_poses /
-                                      pcg_chain_len are left at auto; else 1                                               */
+                                  0 (default) = auto, when pcg_rtol <= 1e-8 (the "exact" mode) and pcg_block_poses / pcg_chain_len
+                                      are left at auto: 2 where it applies with at most 682 edges outside the chain (INTEL,
+                                      MIT, CSAIL, FR079 ...); with more (M3500, FRH: the dense Cholesky is no longer cheap) the
+                                      solve starts with 1 and changes to 2 after an LM iteration whose PCG iteration count
+                                      says PCG costs more than the direct solve (M3500 with DCS: yes, without: no); else 1      */
   int32_t _pad_opt;
 } pgo_options;
 
@@ -341,6 +343,9 @@ typedef struct pgo_handle_info {
   int32_t linear_solver;             /* resolved: 1 = PCG, 2 = direct (chain + low rank)                            */
   int32_t direct_rank;               /* order of the direct solve's dense capacitance matrix (3 x edges outside the chain) */
   int32_t direct_fallbacks;          /* LM iterations whose direct solve gave no usable step and were redone by PCG  */
+  int32_t direct_switched_at;        /* auto, rank above 2048: the LM iteration after which the direct solve took over from PCG
+                                        (its PCG solve cost more than a direct solve of this rank does), 0 = it has not       */
+  int32_t _pad;
 } pgo_handle_info;
 int pgo_get_info(const pgo_t* h, pgo_handle_info* out);                           /* [host] */
 

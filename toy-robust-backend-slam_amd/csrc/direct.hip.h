@@ -733,8 +733,8 @@ __global__ __launch_bounds__(256) void k_dlr_cap(DlrArgs A) {
 //   wavefront 4      factorises the diagonal block kb (its updates are complete: `dwork`) and inverts the factor, every
 //                    workgroup for itself -- nobody waits for another workgroup -- while
 //   wavefronts 0-3   accumulate the workgroup's block: the j are dealt to the four wavefronts, tiles pass through
-//                    wave-private LDS (next tiles requested before the current ones are multiplied), a 4 x 4 register tile
-//                    per lane, the four partial sums added in a fixed order;
+//                    wave-private LDS (next tiles requested before the current ones are multiplied), the 32 x 32 x 32
+//                    products on the matrix cores (v_mfma_f64_16x16x4_f64), the four partial sums added in a fixed order;
 //   type 0 workgroups (block row i > kb of L):  P = C_ik - sum_{j<kb} L_ij L_kj',  L_ik = P L_kk^-T,  dwork_i -= L_ik L_ik'
 //   type 1 workgroups (block column k < kb of row kb of N):  N_kb,k = -L_kk^-1 sum_{j=k}^{kb-1} L_kb,j N_jk
 // Workgroup 0 stores L_kk^-1 = N_kk.
@@ -742,6 +742,8 @@ constexpr int CHOL_T = 32 * 33;                                 // doubles of a 
 constexpr int CHOL_LDS_DOUBLES = 2 * CHOL_T + 32 + 8 * CHOL_T;  // Dm | Li | dinv | 4 waves x (A | B) tiles
 constexpr size_t CHOL_LDS_BYTES = (size_t)CHOL_LDS_DOUBLES * sizeof(double);
 constexpr int CHOL_THREADS = 320;
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane must be wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -763,11 +765,6 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
   const int i = kb + 1 + blockIdx.x;          // type 0: block row of L
   const int kcol = (int)blockIdx.x - n_chol;  // type 1: block column of N
   const bool has_work = type1 ? (kcol < kb) : (i < nb);
-  double acc[4][4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
   // the workgroup's own entries of C_ik and of its diagonal block are requested now, used after the accumulation
   const int pr = (tid & 255) >> 3, pc = 4 * (tid & 7);
   double c_own[4] = {0.0, 0.0, 0.0, 0.0}, d_own[4] = {0.0, 0.0, 0.0, 0.0};
@@ -826,7 +823,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
     // ---- accumulation, j dealt to the four wavefronts
     double* At = tiles + (size_t)w * 2 * CHOL_T;
     double* Bt = At + CHOL_T;
-    const int lx = lane & 7, ly = lane >> 3;
+    const int mr = lane & 15, mq = lane >> 4;
+    v4f64 m00 = {0.0, 0.0, 0.0, 0.0}, m01 = m00, m10 = m00, m11 = m00;
     const int j_lo = type1 ? kcol : 0;
     // rows of the A tile: block row i (type 0) or kb (type 1) of L; B tile: block (kb, j) of L, transposed use (type 0),
     // or block (j, kcol) of N, plain use (type 1)
@@ -862,26 +860,30 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
       }
       wave_lds_sync();
       if (j + 4 < kb) request(j + 4);
-#pragma unroll 4
-      for (int k = 0; k < 32; ++k) {
-        double a[4], b[4];
+      // 32 x 32 x 32 product on the matrix cores: v_mfma_f64_16x16x4_f64, 2 x 2 tiles of 16 x 16, 8 steps of k = 4.  Operand
+      // layout (MI355X_MICROARCH.md): A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15], one f64 per
+      // lane each; C/D: 4 f64 per lane, col = lane & 15, row = (lane >> 4) + 4 reg.  The LDS tiles are k-major, so every
+      // operand is one conflict-free read; against 4 x 4 register tiles on the vector pipe (8 LDS reads per 16 FMAs, LDS
+      // bound with four wavefronts per compute unit) the product needs 1/8 of the LDS reads
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          a[u] = At[k * 33 + 4 * ly + u];
-          b[u] = Bt[k * 33 + 4 * lx + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+      for (int k0 = 0; k0 < 32; k0 += 4) {
+        const double a0 = At[(k0 + mq) * 33 + mr], a1 = At[(k0 + mq) * 33 + 16 + mr];
+        const double b0 = Bt[(k0 + mq) * 33 + mr], b1 = Bt[(k0 + mq) * 33 + 16 + mr];
+        m00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, m00, 0, 0, 0);
+        m01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, m01, 0, 0, 0);
+        m10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, m10, 0, 0, 0);
+        m11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, m11, 0, 0, 0);
       }
     }
     wave_lds_sync();
-    // partial sums -> LDS (the wave's own A tile, now as [r][c])
+    // partial sums -> LDS (the wave's own A tile, now as [r][c]): tile (rt, ct), register g -> row 16 rt + mq + 4 g, col 16 ct + mr
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) At[(4 * ly + u) * 33 + 4 * lx + v] = acc[u][v];
+    for (int g = 0; g < 4; ++g) {
+      At[(mq + 4 * g) * 33 + mr] = m00[g];
+      At[(mq + 4 * g) * 33 + 16 + mr] = m01[g];
+      At[(16 + mq + 4 * g) * 33 + mr] = m10[g];
+      At[(16 + mq + 4 * g) * 33 + 16 + mr] = m11[g];
+    }
   }
   __syncthreads();
   if (blockIdx.x == 0 && tid < 256) {

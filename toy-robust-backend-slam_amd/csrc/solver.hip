@@ -183,6 +183,11 @@ struct pgo_handle {
   bool dl_retry = false;   // the current LM iteration is being redone by PCG after a failed direct solve
   int dl_fallbacks = 0;    // how often that happened
   int dl_fail_at = 0;      // PGO_DIRECT_FAIL_AT (tests): poison the direct solve of this LM iteration
+  bool dl_possible = false;     // auto, rank above DIRECT_AUTO_RANK: the direct solve can take over from PCG (lm_iteration)
+  double dl_est_seconds = 0.0;  // what a direct solve of this rank costs (model fitted to INTEL / FRH / M3500)
+  int dl_switched_at = 0;       // LM iteration after which it first did
+  int dl_last_probe = 0, dl_dear_run = 0;
+  bool dl_ready = false;        // the direct solve's buffers exist
 
   // LM state (TrustRegionMinimizer)
   bool lm_active = false, lin_valid = false, lm_done = false;
@@ -526,9 +531,10 @@ struct pgo_handle {
   int lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, double t0, int k_it, double rel);
   int prepare_system();
   int pcg(int* iters, double* rel);
-  int direct_setup(int32_t N);
+  int direct_setup(int32_t N, bool switch_now = false);
   int direct_solve();
   int factor_chain();
+  int prepare_preconditioner();
   void fill_summary(pgo_summary* s) const;
 };
 
@@ -921,6 +927,10 @@ int pgo_handle::lm_begin() {
   radius = opt.radius0;
   decrease_factor = 2.0;
   last_pcg_iters = 0;
+  if (dl_possible) {   // every solve of the handle takes the same solver decisions (lm_iteration)
+    direct = false;
+    dl_last_probe = dl_dear_run = 0;
+  }
   t_eval = t_asm = t_lin = t_cand = 0;
   recs.clear();
   const double t_begin = wall_s();
@@ -990,13 +1000,15 @@ int pgo_handle::lm_begin() {
 namespace {
 constexpr int DIRECT_MAX_POSES = 65536;
 constexpr int DIRECT_MAX_RANK = 6144;   // 3 x (edges outside the chain) + 1: order of the dense capacitance matrix
+constexpr double PCG_SECONDS_PER_ITER_SMALL = 14e-6;   // a PCG iteration of the two-launch loop on graphs of a few thousand poses
+constexpr int DIRECT_PROBE_EVERY = 10;
 constexpr int DIRECT_AUTO_RANK = 2048;  // auto takes the direct solve up to this rank (INTEL + 50: 918 -> 1.5 ms per LM iteration; FRH, 4515: 13 ms
                                         // against 29 ms of PCG, but one refinement step leaves 5e-8 there; M3500, 5862: 22 ms, the same as PCG)
 }  // namespace
 
-int pgo_handle::direct_setup(int32_t N) {
+int pgo_handle::direct_setup(int32_t N, bool switch_now) {
   const int world = comm ? comm->world : 1;
-  int want = opt.linear_solver;
+  int want = switch_now ? 2 : opt.linear_solver;
   if (const char* de = getenv("PGO_DIRECT")) want = atoi(de) ? 2 : 1;  // experiments: force on / off
   if (want == 1) return PGO_OK;
   if (want != 0 && want != 2) return fail(PGO_ERR_INVALID_ARG, "linear_solver: 0 = auto, 1 = PCG, 2 = direct (chain + low rank)");
@@ -1030,7 +1042,18 @@ int pgo_handle::direct_setup(int32_t N) {
     if (chain[i] < 0) return no("poses " + std::to_string(i) + " and " + std::to_string(i + 1) + " are not joined by an edge");
   dl_m = (int)lr.size();
   dl_K = 3 * dl_m;
-  if (want == 0 && dl_K > DIRECT_AUTO_RANK) return PGO_OK;   // beyond this the dense Cholesky costs what PCG costs (M3500: 22 ms either way)
+  if (want == 0 && dl_K > DIRECT_AUTO_RANK) {
+    // beyond this rank the dense Cholesky is no longer cheap (M3500, 5862: 12.7 ms per LM iteration) and whether PCG beats it
+    // depends on the conditioning, which nobody knows beforehand (M3500 with DCS: 1460 PCG iterations per LM iteration =
+    // 21 ms; without: 230 = 4 ms).  So the handle starts with PCG and lm_iteration() switches to the direct solve once a
+    // PCG solve has cost more than the direct one would (both from counts, not clocks: the decision is reproducible)
+    if (dl_K + 1 <= DIRECT_MAX_RANK) {
+      dl_possible = true;
+      const double kk = dl_K / 5862.0;
+      dl_est_seconds = 1.0e-3 + 11.7e-3 * kk * kk * std::sqrt(kk);
+    }
+    return PGO_OK;
+  }
   if (dl_K + 1 > DIRECT_MAX_RANK) return no(std::to_string(dl_m) + " edges outside the odometry chain (at most " + std::to_string((DIRECT_MAX_RANK - 1) / 3) + ")");
   dl_Kp = std::max(dev::CHOL_NB, ((dl_K + dev::CHOL_NB - 1) / dev::CHOL_NB) * dev::CHOL_NB);
   // separators: the chain is factorised in nsep + 1 pieces side by side (k_dlr_factor is one wavefront's dependent chain:
@@ -1078,6 +1101,7 @@ int pgo_handle::direct_setup(int32_t N) {
   PGOC(dalloc(&dl_Wm, (int64_t)std::max(1, dl_nU) * dl_ld));
   PGOC(sync());  // the host lists die with this scope
   direct = true;
+  dl_ready = true;
   return PGO_OK;
 }
 
@@ -1443,9 +1467,65 @@ int pgo_handle::lm_iteration(bool* stop) {
   PGOC(prepare_system());
   int k_it = 0;
   double rel = 0.0;
-  if (direct) PGOC(direct_solve());
-  else PGOC(pcg(&k_it, &rel));
-  return lm_iteration_tail(stop, R, it0, t0, k_it, rel);
+  // Ranks above DIRECT_AUTO_RANK in auto mode (dl_possible): which solver is cheaper depends on the conditioning and changes
+  // along the trajectory (M3500 without DCS: ~1000 PCG iterations per LM iteration at first, < 100 later; with DCS 1200-2300
+  // throughout), so the handle decides from what it sees -- from iteration COUNTS, not clocks: reproducible --
+  //   on PCG:    two consecutive solves dearer than a direct solve of this rank  -> the direct solve takes over;
+  //   on direct: every DIRECT_PROBE_EVERY-th LM iteration is solved by PCG; if that was cheaper, PCG takes over again.
+  const bool probe = direct && dl_possible && iter - dl_last_probe >= DIRECT_PROBE_EVERY;
+  const bool run_direct = direct && !probe;
+  if (run_direct) {
+    PGOC(direct_solve());
+  } else {
+    if (direct) PGOC(prepare_preconditioner());
+    PGOC(pcg(&k_it, &rel));
+  }
+  if (probe) dl_retry = true;   // (this iteration's step is PCG's: no direct-solve residual, no fallback)
+  const int st_tail = lm_iteration_tail(stop, R, it0, t0, k_it, rel);
+  if (probe) dl_retry = false;
+  if (st_tail == PGO_OK && dl_possible && !run_direct && !*stop) {
+    const bool dear = (double)k_it * PCG_SECONDS_PER_ITER_SMALL > dl_est_seconds;
+    if (probe) {
+      dl_last_probe = iter;
+      if (!dear) {
+        direct = false;
+        dl_dear_run = 0;
+        if (opt.verbose) printf("pgo: %d PCG iterations in LM iteration %d: back to PCG\n", k_it, iter);
+      }
+    } else {
+      dl_dear_run = dear ? dl_dear_run + 1 : 0;
+      if (dl_dear_run >= 2) {
+        if (!dl_ready) PGOC(direct_setup(S.n_poses, true));
+        direct = true;
+        dl_last_probe = iter;
+        if (dl_switched_at == 0) dl_switched_at = iter;
+        if (opt.verbose) printf("pgo: %d PCG iterations in LM iteration %d: the direct solve takes over (rank %d)\n", k_it, iter, dl_K);
+      }
+    }
+  }
+  return st_tail;
+}
+
+// the PCG preconditioner for the current LM diagonal: dense pose-group inverses or the chain factorisation
+int pgo_handle::prepare_preconditioner() {
+  if (grp_B > 1) {
+    dev::GroupPrepArgs GA;
+    GA.inc_ptr = inc_ptr;
+    GA.inc_col = inc_col;
+    GA.hoff = hoff;
+    GA.hd = hd;
+    GA.d2 = d2;
+    GA.ginv = ginv;
+    GA.n_loc = S.n_loc;
+    GA.lo = S.lo;
+    GA.B = grp_B;
+    GA.nb = grp_nb;
+    GA.n_groups = n_groups;
+    hipLaunchKernelGGL(dev::k_prepare_groups, dim3(grp_prep_grid), dim3(dev::WG), grp_lds, stream, GA);
+    PGOC(check_launch("k_prepare_groups"));
+  }
+  if (chain_len) PGOC(factor_chain());
+  return PGO_OK;
 }
 
 // block LDL' of the chain preconditioner's segments (the records are complete: C part from k_assemble, M part from k_prepare)
@@ -1466,23 +1546,7 @@ int pgo_handle::prepare_system() {
                      opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv, (const uint8_t*)fixed_mask, (const int32_t*)prob_of_256,
                      (const double*)prob_radius, chain_len ? chain_c : (double*)nullptr);
   PGOC(check_launch("k_prepare"));
-  if (grp_B > 1) {
-    dev::GroupPrepArgs GA;
-    GA.inc_ptr = inc_ptr;
-    GA.inc_col = inc_col;
-    GA.hoff = hoff;
-    GA.hd = hd;
-    GA.d2 = d2;
-    GA.ginv = ginv;
-    GA.n_loc = S.n_loc;
-    GA.lo = S.lo;
-    GA.B = grp_B;
-    GA.nb = grp_nb;
-    GA.n_groups = n_groups;
-    hipLaunchKernelGGL(dev::k_prepare_groups, dim3(grp_prep_grid), dim3(dev::WG), grp_lds, stream, GA);
-    PGOC(check_launch("k_prepare_groups"));
-  }
-  if (chain_len && !direct) PGOC(factor_chain());   // (the direct solve does not need the preconditioner; its PCG fallback factorises then)
+  if (!direct) PGOC(prepare_preconditioner());   // (the direct solve does not need it; its PCG fallback sets it up on demand)
   return PGO_OK;
 }
 
@@ -1544,7 +1608,7 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
       ++dl_fallbacks;
       int k2 = 0;
       double rel2 = 0.0;
-      int st2 = chain_len ? factor_chain() : PGO_OK;
+      int st2 = prepare_preconditioner();
       if (st2 == PGO_OK) st2 = pcg(&k2, &rel2);
       if (st2 == PGO_OK) st2 = lm_iteration_tail(stop, R, it0, t0, k2, rel2);
       dl_retry = false;
@@ -2019,6 +2083,7 @@ int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   out->linear_solver = h->direct ? 2 : 1;
   out->direct_rank = h->direct ? h->dl_K : 0;
   out->direct_fallbacks = h->dl_fallbacks;
+  out->direct_switched_at = h->dl_switched_at;
   return PGO_OK;
 }
 
