@@ -374,6 +374,7 @@ def main():
                     sm = sv.solve()
                     if best is None or sm.seconds_total < best[0].seconds_total:
                         best = (sm, sv.poses())
+                run.info = sv.info()
                 sv.close()
                 return best
 
@@ -394,10 +395,9 @@ def main():
                 for name in ("MIT", "M3500"):
                     gd = P.ReadG2O(os.path.join(data, name + ".g2o"))
                     for m in (1, 0):
-                        sv = P.Solver(gd, P.Options(method=m, pcg_max_iters=400000), device=local_rank)
-                        solver = "direct" if sv.info().linear_solver == 2 else "PCG rtol 1e-10"
-                        sv.close()
                         sm, px = run(gd, method=m, pcg_max_iters=400000)
+                        solver = ("direct" if run.info.direct_switched_at == 0 else "PCG rtol 1e-10 and direct in turns, first change after LM iteration %d"
+                                  % run.info.direct_switched_at) if (run.info.linear_solver == 2 or run.info.direct_switched_at) else "PCG rtol 1e-10"
                         ref = np.load(os.path.join(golden, "lm_%s_out0_m%d_poses.npy" % (name, m)))
                         wl["%s METHOD %d (exact: %s)" % (name, m, solver)] = {
                             "gn_it_per_s": sm.iterations / sm.seconds_total, "iterations": sm.iterations, "pcg_iters": sm.total_pcg_iters,
