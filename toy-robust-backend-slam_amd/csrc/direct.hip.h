@@ -1,6 +1,7 @@
-// Direct solve of the LM system (H + D'D) y = g for small chain-like graphs (the reference's own datasets: INTEL, MIT,
-// CSAIL, FR079 -- BASELINE configs[0]-[2]), standing in for the reference's SPARSE_NORMAL_CHOLESKY (main.cpp:154-163)
-// where block-Jacobi PCG needs hundreds of latency-bound iterations per LM iteration.
+// Direct solve of the LM system (H + D'D) y = g for chain-like graphs (the reference's own datasets: INTEL, MIT, CSAIL,
+// FR079 -- BASELINE configs[0]-[2]; any long odometry chain with up to ~2000 other edges), standing in for the reference's
+// SPARSE_NORMAL_CHOLESKY (main.cpp:154-163) where block-Jacobi PCG needs hundreds of latency-bound iterations per LM
+// iteration.
 //
 // With S the Jacobi column scaling, split the edges into the odometry CHAIN (one edge per consecutive pose pair) and
 // the rest (loop closures, bogus loops, extra short-range edges: m of them):
@@ -8,14 +9,18 @@
 //                                                                               constant pose),
 //                              V = the 3m x 3N matrix of the scaled Jacobian rows of the other edges.
 // Woodbury:  y = t - Z w,  t = T^-1 g,  Z = T^-1 V',  (I + V Z) w = V t.   Steps, all in fp64 and in a fixed order:
-//     k_dlr_setup    per pose the blocks M_i, C_i of T; per low-rank edge its two scaled 3x3 Jacobian blocks
-//     k_dlr_factor   block LDL' of T:  W_i = C_i S_{i-1}^-1,  S_i = M_i - W_i C_i'   (one wavefront, records through LDS)
-//     k_dlr_cols     Z and t: one lane per right-hand side sweeps the chain forward and backward (3m + 1 columns)
-//     k_dlr_cap      capacitance matrix I + V Z (dense, order 3m) and the right-hand side V t
-//     k_chol_panel   left-looking blocked Cholesky of it (32 x 32 blocks, one launch per block column)
-//     k_chol_solve   the two triangular solves (one workgroup)
-//     k_dlr_combine  y = t - Z w
-// followed by steps of iterative refinement against the assembled block-CSR matrix (k_spmv), which bring the solution to
+//     k_dlr_setup      per pose the blocks M_i, C_i of T; per low-rank edge its two scaled 3x3 Jacobian blocks
+//     k_dlr_factor     block LDL' of T:  W_i = C_i S_{i-1}^-1,  S_i = M_i - W_i C_i'  -- one wavefront per PIECE of the chain
+//                      between separator poses (nested dissection; the separators come back through k_dlr_sep_*)
+//     k_dlr_prefix, k_dlr_fwd / _mid / _fix
+//                      Z and t: one lane per right-hand side, the sweeps over the chain cut into 32 segments side by side
+//     k_dlr_sep_*      the separators' Schur complement (order 3 per separator, SPD) and its correction of every column
+//     k_dlr_cap        capacitance matrix I + V Z (dense, order 3m) and the right-hand side V t
+//     k_chol_panel     left-looking blocked Cholesky of it with the explicit inverse (32 x 32 blocks, one launch per block
+//                      column, the block products on the fp64 matrix cores)
+//     k_tri_apply      the two triangular solves as products with the inverse factor
+//     k_dlr_combine    y = t - Z w
+// followed by a step of iterative refinement against the assembled block-CSR matrix (k_spmv), which brings the solution to
 // the accuracy of a backward-stable direct solve (the capacitance matrix reaches condition 1e7 at large trust-region
 // radii).  Restated in numpy and checked against the oracle's SuperLU solve: tests/test_direct_solve_math.py.
 #pragma once
