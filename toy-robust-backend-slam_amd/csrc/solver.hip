@@ -1049,8 +1049,10 @@ int pgo_handle::direct_setup(int32_t N, bool switch_now) {
     // PCG solve has cost more than the direct one would (both from counts, not clocks: the decision is reproducible)
     if (dl_K + 1 <= DIRECT_MAX_RANK) {
       dl_possible = true;
+      // cost model of a direct solve: the capacitance Cholesky (M3500, rank 5862: 11.7 ms; ~ rank^2.5 between INTEL, FRH and
+      // M3500) + the chain (factorisation and sweeps: 0.15 us per pose, 5k .. 40k-pose chains) + 1 ms of fixed latencies
       const double kk = dl_K / 5862.0;
-      dl_est_seconds = 1.0e-3 + 11.7e-3 * kk * kk * std::sqrt(kk);
+      dl_est_seconds = 1.0e-3 + 11.7e-3 * kk * kk * std::sqrt(kk) + 0.15e-6 * N;
     }
     return PGO_OK;
   }
@@ -1484,7 +1486,8 @@ int pgo_handle::lm_iteration(bool* stop) {
   const int st_tail = lm_iteration_tail(stop, R, it0, t0, k_it, rel);
   if (probe) dl_retry = false;
   if (st_tail == PGO_OK && dl_possible && !run_direct && !*stop) {
-    const bool dear = (double)k_it * PCG_SECONDS_PER_ITER_SMALL > dl_est_seconds;
+    // a PCG iteration: 14 us on graphs of a few thousand poses (two launches), 39 us at 100k poses
+    const bool dear = (double)k_it * (PCG_SECONDS_PER_ITER_SMALL + 0.25e-9 * S.n_poses) > dl_est_seconds;
     if (probe) {
       dl_last_probe = iter;
       if (!dear) {
