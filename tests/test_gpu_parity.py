@@ -393,6 +393,20 @@ def test_direct_solve_other_options_and_reproducibility(pgo, oracle):
         s.close()
     assert res[2][3] == 3 * (128 + 1) and res[2][2] == res[1][2]
     assert res[2][1] == pytest.approx(res[1][1], rel=1e-9) and np.abs(res[2][0] - res[1][0]).max() < 1e-7
+    # tiny graphs: fewer poses than sweep segments, no separators (the first 9 / 40 poses of INTEL with their edges + one loop)
+    for n_small in (9, 40):
+        gi_ia, gi_ib = np.array(gi.ia), np.array(gi.ib)
+        keep = [k for k in range(gi.n_edges) if gi_ia[k] < n_small and gi_ib[k] < n_small]
+        ia_s, ib_s = np.append(gi_ia[keep], 0), np.append(gi_ib[keep], n_small - 1)
+        meas_s = np.vstack([np.array(gi.meas)[keep], [[0.1, 0.0, 0.05]]])
+        gs_ = pgo.Graph.from_arrays(np.array(gi.poses)[:n_small], ia_s, ib_s, meas_s, np.append(np.array(gi.kind)[keep], 1))
+        res = {}
+        for ls in (2, 1):
+            s = pgo.Solver(gs_, pgo.Options(method=1, max_iters=6, linear_solver=ls, pcg_rtol=1e-12))
+            sm = s.solve()
+            res[ls] = (s.poses(), sm.final_cost)
+            s.close()
+        assert res[2][1] == pytest.approx(res[1][1], rel=1e-9) and np.abs(res[2][0] - res[1][0]).max() < 1e-8
     # a graph without any edge outside the chain (pure odometry): rank 0, the chain factorisation alone is the solve
     keep = [k for k in range(g.n_edges) if abs(int(g.ia[k]) - int(g.ib[k])) == 1]
     gc = pgo.Graph.from_arrays(np.array(g.poses), np.array(g.ia)[keep], np.array(g.ib)[keep], np.array(g.meas)[keep], np.array(g.kind)[keep])
