@@ -188,6 +188,8 @@ struct pgo_handle {
   int dl_switched_at = 0;       // LM iteration after which it first did
   int dl_last_probe = 0, dl_dear_run = 0;
   bool dl_ready = false;        // the direct solve's buffers exist
+  hipGraphExec_t dl_graph_exec = nullptr;   // the captured direct solve
+  bool dl_graph_failed = false;
 
   // LM state (TrustRegionMinimizer)
   bool lm_active = false, lin_valid = false, lm_done = false;
@@ -203,6 +205,7 @@ struct pgo_handle {
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
     for (void* p : allocs) (void)hipFree(p);
     if (cg_graph_exec) (void)hipGraphExecDestroy(cg_graph_exec);
+    if (dl_graph_exec) (void)hipGraphExecDestroy(dl_graph_exec);
     if (h_st) (void)hipHostFree(h_st);
     if (h_scal) (void)hipHostFree(h_scal);
     if (h_solo) (void)hipHostFree(h_solo);
@@ -533,6 +536,7 @@ struct pgo_handle {
   int pcg(int* iters, double* rel);
   int direct_setup(int32_t N, bool switch_now = false);
   int direct_solve();
+  int direct_enqueue();
   int factor_chain();
   int prepare_preconditioner();
   void fill_summary(pgo_summary* s) const;
@@ -1110,7 +1114,7 @@ int pgo_handle::direct_setup(int32_t N, bool switch_now) {
 
 // (H + D'D) y = gs by Woodbury on chain + low rank, then iterative refinement against the assembled matrix; leaves the
 // true residual in r (the model-decrease identity of lm_iteration_tail reads it) and |r|^2, |gs|^2 in scal[8..9].
-int pgo_handle::direct_solve() {
+int pgo_handle::direct_enqueue() {
   const int n = S.n_loc, K = dl_K, Kp = dl_Kp, nb = dl_Kp / 32;
   dev::DlrArgs A;
   A.n = n;
@@ -1252,9 +1256,35 @@ int pgo_handle::direct_solve() {
   hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)r, (const double*)r, part[2]);
   hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)gs, (const double*)gs, part[4]);
   PGOC(check_launch("k_dot"));
-  if (dl_fail_at > 0 && iter == dl_fail_at)   // test hook (PGO_DIRECT_FAIL_AT): a direct solve that returns NaNs
-    HIPC(hipMemsetAsync(y, 0xFF, (size_t)3 * n * sizeof(double), stream));
   return reduce_to_scal({{part[2], g_flat, 0}, {part[4], g_flat, 0}}, 8);
+}
+
+// The ~130 launches of a direct solve are the same every time (every argument is fixed for the handle's lifetime; the
+// trust-region radius enters through d2 on the device): captured once into a hipGraph and replayed with one host call.
+int pgo_handle::direct_solve() {
+  if (opt.use_graphs && !dl_graph_failed) {
+    if (!dl_graph_exec) {
+      hipGraph_t gr = nullptr;
+      HIPC(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      const int st_cap = direct_enqueue();
+      const hipError_t e_end = hipStreamEndCapture(stream, &gr);
+      hipError_t e_inst = hipSuccess;
+      if (st_cap == PGO_OK && e_end == hipSuccess) {
+        e_inst = hipGraphInstantiate(&dl_graph_exec, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+      }
+      if (st_cap != PGO_OK || e_end != hipSuccess || e_inst != hipSuccess) {   // eager launches from here on
+        (void)hipGetLastError();
+        dl_graph_exec = nullptr;
+        dl_graph_failed = true;
+      }
+    }
+    if (dl_graph_exec) HIPC(hipGraphLaunch(dl_graph_exec, stream));
+  }
+  if (!dl_graph_exec) PGOC(direct_enqueue());
+  if (dl_fail_at > 0 && iter == dl_fail_at)   // test hook (PGO_DIRECT_FAIL_AT): a direct solve that returns NaNs
+    HIPC(hipMemsetAsync(y, 0xFF, (size_t)3 * S.n_loc * sizeof(double), stream));
+  return PGO_OK;
 }
 
 // block-Jacobi PCG on (H + D2) y = gs, y0 = 0.  Host checks the residual every
