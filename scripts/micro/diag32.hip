@@ -219,12 +219,73 @@ __device__ void diag_v8(double* Dm, double* Li, int lane) {
     }
   }
 }
+
+// variant 9: TWO wavefronts.  Wave 0 factorises (L D L', rows in registers, v_readlane) and hands every finished column of
+// Lt to wave 1 through LDS; wave 1 eliminates that column from the inverse one step behind.  The two 32-step loops of
+// variant 7 run side by side instead of one after the other inside each step.
+__device__ void diag_v9(double* Dm, double* Li, double* colL, volatile int* flag, int tid) {
+  const int w = tid >> 6, lane = tid & 63, row = lane & 31;
+  if (w == 0) {
+    double a[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) a[c] = Dm[row * 33 + c];
+    double dsel = 1.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const double d = readlane_f64(a[k], k);
+      const double rd = fast_rcp(d);
+      dsel = (row == k) ? d : dsel;
+      const double ak = a[k];
+      const double l = (row > k) ? ak * rd : 0.0;
+      a[k] = l;
+      if (lane < 32) colL[k * 32 + row] = l;
+      wave_lds_sync();
+      if (lane == 0) __hip_atomic_store((int*)flag, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS operations of one wavefront complete in order)
+#pragma unroll
+      for (int c = k + 1; c < 32; ++c) a[c] -= l * readlane_f64(ak, c);
+    }
+    const double sd = sqrt(dsel), isd = 1.0 / sd;
+    if (lane < 32) {
+      colL[32 * 32 + row] = isd;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const double sc = readlane_f64(sd, c);
+        Dm[row * 33 + c] = (c < row) ? a[c] * sc : ((c == row) ? sd : 0.0);
+      }
+    }
+    wave_lds_sync();
+    if (lane == 0) __hip_atomic_store((int*)flag, 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else if (w == 1) {
+    double n[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) n[c] = (c == row) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      int spins = 0;
+      while (__hip_atomic_load((int*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k && ++spins < (1 << 20)) {}
+      wave_lds_sync();
+      const double l = colL[k * 32 + row];
+#pragma unroll
+      for (int c = 0; c <= k; ++c) n[c] -= l * readlane_f64(n[c], k);
+    }
+    int spins = 0;
+    while (__hip_atomic_load((int*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 33 && ++spins < (1 << 20)) {}
+    wave_lds_sync();
+    const double isd = colL[32 * 32 + row];
+    if (lane < 32) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) Li[row * 33 + c] = n[c] * isd;
+    }
+  }
+}
 template <int V>
-__global__ __launch_bounds__(V == 2 ? 256 : 64) void k_diag(const double* in, double* outL, double* outI, int reps) {
-  __shared__ double Dm[32 * 33], Li[32 * 33], dinv[32], colb[64];
+__global__ __launch_bounds__(V == 2 ? 256 : (V == 9 ? 128 : 64)) void k_diag(const double* in, double* outL, double* outI, int reps) {
+  __shared__ double Dm[32 * 33], Li[32 * 33], dinv[32], colb[64], colL[33 * 32];
+  __shared__ int flag9;
   const int tid = threadIdx.x, lane = tid & 63;
   for (int rep = 0; rep < reps; ++rep) {
     for (int e = tid; e < 1024; e += blockDim.x) Dm[(e >> 5) * 33 + (e & 31)] = in[e];
+    if (tid == 0) flag9 = 0;
     __syncthreads();
     if (V == 0) {
       const int row = lane & 31;
@@ -251,6 +312,8 @@ __global__ __launch_bounds__(V == 2 ? 256 : 64) void k_diag(const double* in, do
       diag_v3(Dm, Li, lane);
     } else if (V == 4) {
       diag_v4<0>(Dm, Li, lane);
+    } else if (V == 9) {
+      diag_v9(Dm, Li, colL, &flag9, tid);
     } else if (V == 7) {
       diag_v7(Dm, Li, lane);
     } else if (V == 8) {
@@ -322,7 +385,7 @@ int main() {
   hipMemcpy(dA, A.data(), 8192, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int reps = 200;
-  for (int v = 7; v < 9; ++v) {
+  for (int v = 7; v < 10; v += 2) {
     for (int pass = 0; pass < 2; ++pass) {
       hipEventRecord(e0);
       if (v == 0) hipLaunchKernelGGL(k_diag<0>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
@@ -334,6 +397,7 @@ int main() {
       if (v == 6) hipLaunchKernelGGL(k_diag<6>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
       if (v == 7) hipLaunchKernelGGL(k_diag<7>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
       if (v == 8) hipLaunchKernelGGL(k_diag<8>, dim3(1), dim3(64), 0, 0, dA, dL, dI, reps);
+      if (v == 9) hipLaunchKernelGGL(k_diag<9>, dim3(1), dim3(128), 0, 0, dA, dL, dI, reps);
       hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void k_dlr_cap(DlrArgs A) {
 // N = L^-1 (the two triangular solves then are two dense, fully parallel products instead of 2 x nb dependent steps in
 // one workgroup: 200 us -> a few us per solve; the refinement against the assembled matrix absorbs the difference
 // between substitution and a product with the inverse).  One launch per block column kb; workgroups of 5 wavefronts:
-//   wavefront 4      factorises the diagonal block kb (its updates are complete: `dwork`) and inverts the factor, every
+//   wavefronts 4, 5  factorise the diagonal block kb (its updates are complete: `dwork`) and invert the factor, every
 //                    workgroup for itself -- nobody waits for another workgroup -- while
 //   wavefronts 0-3   accumulate the workgroup's block: the j are dealt to the four wavefronts, tiles pass through
 //                    wave-private LDS (next tiles requested before the current ones are multiplied), the 32 x 32 x 32
@@ -744,9 +744,9 @@ __global__ __launch_bounds__(256) void k_dlr_cap(DlrArgs A) {
 //   type 1 workgroups (block column k < kb of row kb of N):  N_kb,k = -L_kk^-1 sum_{j=k}^{kb-1} L_kb,j N_jk
 // Workgroup 0 stores L_kk^-1 = N_kk.
 constexpr int CHOL_T = 32 * 33;                                 // doubles of a padded 32 x 32 LDS tile
-constexpr int CHOL_LDS_DOUBLES = 2 * CHOL_T + 32 + 8 * CHOL_T;  // Dm | Li | dinv | 4 waves x (A | B) tiles
+constexpr int CHOL_LDS_DOUBLES = 2 * CHOL_T + 32 + 8 * CHOL_T + 33 * 32 + 2;  // Dm | Li | dinv | 4 waves x (A | B) tiles | Lt columns + 1 / sqrt(D) | counter
 constexpr size_t CHOL_LDS_BYTES = (size_t)CHOL_LDS_DOUBLES * sizeof(double);
-constexpr int CHOL_THREADS = 320;
+constexpr int CHOL_THREADS = 384;
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
@@ -763,6 +763,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
   double* Li = sm + CHOL_T;        // [32][33]
   double* dinv = sm + 2 * CHOL_T;  // [32]
   double* tiles = sm + 2 * CHOL_T + 32;
+  double* colL = tiles + 8 * CHOL_T;                       // [33][32]: the columns of Lt as they are finished, then 1 / sqrt(D)
+  int* pflag = reinterpret_cast<int*>(colL + 33 * 32);     // columns handed over so far (33: the scaling too)
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63;
   const int n_chol = nb - 1 - kb;
@@ -780,8 +782,10 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
       d_own[v] = dwork[(int64_t)i * 1024 + pr * 32 + pc + v];
     }
   }
+  if (tid == 0) *pflag = 0;
+  __syncthreads();
   if (w == 4) {
-    // ---- diagonal block: L_kk (Dm) and its inverse (Li), one wavefront: L D L' and the inverse of the unit triangle in
+    // ---- diagonal block: L_kk (Dm) and its inverse (Li): L D L' and the inverse of the unit triangle, first written as
     // ONE 32-step loop with the rows of both in registers (lane r: row r of the block and row r of N), v_readlane
     // broadcasts only.  Step k scales column k, updates the trailing entries a_rc -= Lt_rk (Lt_ck D_k), c > k, and
     // eliminates column k from the inverse, N_r. -= Lt_rk N_k. (row k of N is final by then).  No LDS access and no
@@ -789,15 +793,15 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
     // afterwards.  scripts/micro/diag32.hip measured the alternatives on one 32 x 32 block: this form 11.7 us, rows in
     // registers + inverse through LDS 22.8 us, 256 threads with everything in LDS and workgroup barriers 19.6 us,
     // one wavefront with everything in LDS 49 us.
+    // The two halves of every step run in TWO wavefronts: this one factorises and hands each finished column of Lt to
+    // wavefront 5 through LDS (column + a counter; LDS operations of one wavefront complete in order), which eliminates it
+    // from the inverse one step behind (scripts/micro/diag32.hip: 12.0 -> 9.8 us).
     for (int e = lane; e < 1024; e += 64) Dm[(e >> 5) * 33 + (e & 31)] = dwork[(int64_t)kb * 1024 + e];
     wave_lds_sync();
     const int row = lane & 31;
-    double a[32], n[32];
+    double a[32];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      a[c] = Dm[row * 33 + c];
-      n[c] = (c == row) ? 1.0 : 0.0;
-    }
+    for (int c = 0; c < 32; ++c) a[c] = Dm[row * 33 + c];
     double dsel = 1.0;
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
@@ -809,20 +813,47 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict_
       const double ak = a[k];
       const double l = (row > k) ? ak * rd : 0.0;   // Lt_rk (0 on and above the diagonal: those rows are finished)
       a[k] = l;
+      if (lane < 32) colL[k * 32 + row] = l;
+      wave_lds_sync();
+      if (lane == 0) __hip_atomic_store(pflag, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
       for (int c = k + 1; c < 32; ++c) a[c] -= l * readlane_f64(ak, c);
-#pragma unroll
-      for (int c = 0; c <= k; ++c) n[c] -= l * readlane_f64(n[c], k);
     }
     const double sd = sqrt(dsel), isd = 1.0 / sd;
-    wave_lds_sync();
     if (lane < 32) {
+      colL[32 * 32 + row] = isd;
 #pragma unroll
       for (int c = 0; c < 32; ++c) {
         const double sc = readlane_f64(sd, c);
         Dm[row * 33 + c] = (c < row) ? a[c] * sc : ((c == row) ? sd : 0.0);
-        Li[row * 33 + c] = n[c] * isd;
       }
+    }
+    wave_lds_sync();
+    if (lane == 0) __hip_atomic_store(pflag, 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else if (w == 5) {
+    // ---- the inverse of the unit triangle, one step behind the factorisation: N_r. -= Lt_rk N_k. (row k of N is final
+    // by then), rows in registers, v_readlane broadcasts; N = sqrt(D)^-1 Lt^-1 at the end.  The waits are bounded: a lost
+    // hand-over would give wrong numbers (the tests see them), never a hang
+    const int row = lane & 31;
+    double n[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) n[c] = (c == row) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      int spins = 0;
+      while (__hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k && ++spins < (1 << 22)) {}
+      wave_lds_sync();
+      const double l = colL[k * 32 + row];
+#pragma unroll
+      for (int c = 0; c <= k; ++c) n[c] -= l * readlane_f64(n[c], k);
+    }
+    int spins = 0;
+    while (__hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 33 && ++spins < (1 << 22)) {}
+    wave_lds_sync();
+    const double isd = colL[32 * 32 + row];
+    if (lane < 32) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) Li[row * 33 + c] = n[c] * isd;
     }
   } else if (has_work) {
     // ---- accumulation, j dealt to the four wavefronts
