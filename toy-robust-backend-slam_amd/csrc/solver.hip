@@ -190,6 +190,7 @@ struct pgo_handle {
   bool dl_ready = false;        // the direct solve's buffers exist
   hipGraphExec_t dl_graph_exec = nullptr;   // the captured direct solve
   bool dl_graph_failed = false;
+  bool dl_use_graph = false;   // PGO_DIRECT_GRAPH=1
 
   // LM state (TrustRegionMinimizer)
   bool lm_active = false, lin_valid = false, lm_done = false;
@@ -1068,7 +1069,10 @@ int pgo_handle::direct_setup(int32_t N, bool switch_now) {
   {
     const char* se = getenv("PGO_DIRECT_SEP");
     if (N >= 256 && !(se && se[0] == '0')) {
-      dl_nsep = std::min(dev::DLR_MAX_SEP, std::max(3, (int)(N / 400) - 1));   // pieces of ~300-400 poses, at least 4 of them
+      // 3 separators up to ~5000 poses (INTEL / MIT: 3 -> 826 / 2392 GN it/s, 5 -> 813 / 2294, 7 -> 788 / 2116, 15 -> 606 / 1209:
+      // every separator adds 3 columns and a row of the Schur system), then one per ~1200 poses (40k poses: 3 -> 156, 15 -> 205)
+      dl_nsep = std::min(dev::DLR_MAX_SEP, std::max(3, (int)(N / 1200)));
+      if (const char* ne = getenv("PGO_DIRECT_NSEP")) dl_nsep = std::min(dev::DLR_MAX_SEP, std::max(1, atoi(ne)));   // experiments
       for (int j = 0; j < dl_nsep; ++j) dl_sep[j] = (int)(((int64_t)(j + 1) * N) / (dl_nsep + 1));
     }
   }
@@ -1077,6 +1081,7 @@ int pgo_handle::direct_setup(int32_t N, bool switch_now) {
   dl_refine = 1;   // (a second step does not lower FRH's 5e-8: that residual is what the conditioning allows)
   if (const char* re = getenv("PGO_DIRECT_REFINE")) dl_refine = std::max(0, atoi(re));
   if (const char* fa = getenv("PGO_DIRECT_FAIL_AT")) dl_fail_at = atoi(fa);
+  if (const char* ge = getenv("PGO_DIRECT_GRAPH")) dl_use_graph = ge[0] == '1';
   PGOC(dalloc(&dl_chain_edge, N));
   PGOC(dalloc(&dl_lr_edge, std::max(1, dl_m)));
   PGOC(dalloc(&dl_va, std::max(1, dl_m)));
@@ -1260,9 +1265,11 @@ int pgo_handle::direct_enqueue() {
 }
 
 // The ~130 launches of a direct solve are the same every time (every argument is fixed for the handle's lifetime; the
-// trust-region radius enters through d2 on the device): captured once into a hipGraph and replayed with one host call.
+// trust-region radius enters through d2 on the device), so they can be captured once into a hipGraph and replayed with
+// one host call -- measured: no gain in GN it/s (the solve is bound by its dependent kernels, not by the host), while
+// capture + instantiation cost ~5 ms, as much as five LM iterations of a fresh handle.  Off unless PGO_DIRECT_GRAPH=1.
 int pgo_handle::direct_solve() {
-  if (opt.use_graphs && !dl_graph_failed) {
+  if (opt.use_graphs && dl_use_graph && !dl_graph_failed) {
     if (!dl_graph_exec) {
       hipGraph_t gr = nullptr;
       HIPC(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
