@@ -273,11 +273,12 @@ struct DlrColsArgs {
   double* E2;  // [nseg][3][ld]
 };
 
-// prefix products of one segment per thread: threads 0 .. nseg-1 forward (G), 64 .. 64+nseg-1 backward (Gb)
-__global__ __launch_bounds__(128) void k_dlr_prefix(const double* __restrict__ fac, int n, int nseg, int seglen, double* __restrict__ pre) {
+// prefix products of one segment per thread: the first half of the workgroup forward (G), the second half backward (Gb)
+__global__ __launch_bounds__(512) void k_dlr_prefix(const double* __restrict__ fac, int n, int nseg, int seglen, double* __restrict__ pre) {
   const int t = threadIdx.x;
-  const bool back = t >= 64;
-  const int s = back ? t - 64 : t;
+  const int half = blockDim.x >> 1;
+  const bool back = t >= half;
+  const int s = back ? t - half : t;
   if (s >= nseg) return;
   const int i0 = s * seglen, i1 = min(n, i0 + seglen);
   double g[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -702,6 +703,173 @@ __global__ __launch_bounds__(256) void k_dlr_sep_apply(DlrSepArgs A) {
           for (int b = 0; b < DLR_MAX_U; ++b) out = (b == su) ? w[b] : out;
         }
         A.X[(int64_t)r * A.ld + j] = out;
+      }
+    }
+  }
+}
+
+// ---- T^-1 r for ONE right-hand side (the refinement's residual) in one launch: the batched kernels above take three
+// launches + two for the separators, ~120 us of mostly latency for a single column.  One workgroup, thread s = segment s of
+// a FINER segmentation (256 segments, prefix products `pre2`): local forward sweeps, the segment-end states joined by a
+// Hillis-Steele scan of the affine maps (a, F) -> (a + F a', F F') in LDS, local backward sweeps on the true t, the
+// mirrored scan, the corrections, and the separators' Schur step (k_dlr_sep_*) -- everything between workgroup barriers.
+// The column lives in a plain vector x[3n].  Used while a segment has at most 16 poses (n <= 4096).
+struct DlrSolve1Args {
+  const double* fac;
+  const double* pre2;
+  int32_t n, nseg, seglen;
+  const double* rhs_b;
+  const double* rhs_sub;
+  double* x;            // [3n]
+  int32_t nsep, nU;
+  int32_t sep[DLR_MAX_SEP];
+  const double* ksep;
+  const double* trec;
+  const double* Y;
+  int32_t yld;
+  const double* Sinv;
+};
+__global__ __launch_bounds__(256) void k_dlr_solve1(DlrSolve1Args A) {
+  __shared__ double sa[2][256 * 3];
+  __shared__ double sF[2][256 * 9];
+  __shared__ double sg[DLR_MAX_U], sw[DLR_MAX_U];
+  const int s = threadIdx.x;
+  const int n = A.n, L = A.seglen;
+  const int i0 = min(n, s * L), i1 = min(n, i0 + L);
+  const bool live = s < A.nseg && i1 > i0;
+  // 1. local forward sweep
+  double t0 = 0, t1 = 0, t2 = 0;
+  for (int i = i0; i < i1; ++i) {
+    double r0 = A.rhs_b[3 * i], r1 = A.rhs_b[3 * i + 1], r2 = A.rhs_b[3 * i + 2];
+    if (A.rhs_sub) { r0 -= A.rhs_sub[3 * i]; r1 -= A.rhs_sub[3 * i + 1]; r2 -= A.rhs_sub[3 * i + 2]; }
+    const double* W = A.fac + (int64_t)i * DLR_REC;
+    const double n0 = r0 - (W[0] * t0 + W[1] * t1 + W[2] * t2);
+    const double n1 = r1 - (W[3] * t0 + W[4] * t1 + W[5] * t2);
+    const double n2 = r2 - (W[6] * t0 + W[7] * t1 + W[8] * t2);
+    t0 = n0; t1 = n1; t2 = n2;
+    A.x[3 * i] = t0; A.x[3 * i + 1] = t1; A.x[3 * i + 2] = t2;
+  }
+  // scan of the affine maps: (a, F)_s <- (a_s + F_s a_{s-d}, F_s F_{s-d}); dead segments are the identity map
+  auto scan = [&](double (&a)[3], double (&F)[9], bool reverse) {
+    int cur = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sa[0][3 * s + c] = a[c];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) sF[0][9 * s + c] = F[c];
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int o = reverse ? s + d : s - d;
+      double na[3], nF[9];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) na[c] = sa[cur][3 * s + c];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) nF[c] = sF[cur][9 * s + c];
+      if (o >= 0 && o < 256) {
+        const double* ao = &sa[cur][3 * o];
+        const double* Fo = &sF[cur][9 * o];
+        double ta[3], tF[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          ta[r] = na[r] + nF[3 * r] * ao[0] + nF[3 * r + 1] * ao[1] + nF[3 * r + 2] * ao[2];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) tF[3 * r + c] = nF[3 * r] * Fo[c] + nF[3 * r + 1] * Fo[3 + c] + nF[3 * r + 2] * Fo[6 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) na[c] = ta[c];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) nF[c] = tF[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sa[cur ^ 1][3 * s + c] = na[c];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) sF[cur ^ 1][9 * s + c] = nF[c];
+      cur ^= 1;
+      __syncthreads();
+    }
+    return cur;
+  };
+  double a[3] = {t0, t1, t2};
+  double F[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (live) {
+    const double* G = A.pre2 + (int64_t)(i1 - 1) * DLR_PRE;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) F[c] = G[c];
+  } else {
+    a[0] = a[1] = a[2] = 0.0;
+  }
+  int cur = scan(a, F, false);
+  // t entering the segment = the scanned state of the segment before
+  double ti0 = 0, ti1 = 0, ti2 = 0;
+  if (s > 0) { ti0 = sa[cur][3 * (s - 1)]; ti1 = sa[cur][3 * (s - 1) + 1]; ti2 = sa[cur][3 * (s - 1) + 2]; }
+  __syncthreads();
+  // 2. local backward sweep on the true t
+  double z0 = 0, z1 = 0, z2 = 0;
+  for (int i = i1 - 1; i >= i0; --i) {
+    const double* G = A.pre2 + (int64_t)i * DLR_PRE;
+    const double u0 = A.x[3 * i] + (G[0] * ti0 + G[1] * ti1 + G[2] * ti2);
+    const double u1 = A.x[3 * i + 1] + (G[3] * ti0 + G[4] * ti1 + G[5] * ti2);
+    const double u2 = A.x[3 * i + 2] + (G[6] * ti0 + G[7] * ti1 + G[8] * ti2);
+    const double* Fc = A.fac + (int64_t)i * DLR_REC;
+    const double* Wn = A.fac + (int64_t)(i + 1) * DLR_REC;   // record n is all zero
+    const double n0 = Fc[9] * u0 + Fc[10] * u1 + Fc[11] * u2 - (Wn[0] * z0 + Wn[3] * z1 + Wn[6] * z2);
+    const double n1 = Fc[10] * u0 + Fc[12] * u1 + Fc[13] * u2 - (Wn[1] * z0 + Wn[4] * z1 + Wn[7] * z2);
+    const double n2 = Fc[11] * u0 + Fc[13] * u1 + Fc[14] * u2 - (Wn[2] * z0 + Wn[5] * z1 + Wn[8] * z2);
+    z0 = n0; z1 = n1; z2 = n2;
+    A.x[3 * i] = z0; A.x[3 * i + 1] = z1; A.x[3 * i + 2] = z2;
+  }
+  a[0] = live ? z0 : 0.0; a[1] = live ? z1 : 0.0; a[2] = live ? z2 : 0.0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) F[c] = (c % 4 == 0) ? 1.0 : 0.0;
+  if (live) {
+    const double* G = A.pre2 + (int64_t)i0 * DLR_PRE + 9;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) F[c] = G[c];
+  }
+  cur = scan(a, F, true);
+  double x0 = 0, x1 = 0, x2 = 0;
+  if (s + 1 < 256) { x0 = sa[cur][3 * (s + 1)]; x1 = sa[cur][3 * (s + 1) + 1]; x2 = sa[cur][3 * (s + 1) + 2]; }
+  // 3. x_i += Gb_i x_in
+  for (int i = i0; i < i1; ++i) {
+    const double* G = A.pre2 + (int64_t)i * DLR_PRE + 9;
+    A.x[3 * i] += G[0] * x0 + G[1] * x1 + G[2] * x2;
+    A.x[3 * i + 1] += G[3] * x0 + G[4] * x1 + G[5] * x2;
+    A.x[3 * i + 2] += G[6] * x0 + G[7] * x1 + G[8] * x2;
+  }
+  if (A.nsep == 0) return;
+  // 4. the separators: w = S^-1 (Ms x_s - C_s x_{s-1} - C_{s+1}' x_{s+1}),  x -= Y w,  x_s = w
+  __syncthreads();   // (the workgroup's global writes above are visible to all its threads after the barrier)
+  if (s < A.nU) {
+    const int j = s / 3, c = s - 3 * j, sp = A.sep[j];
+    const double* ks = A.ksep + (int64_t)j * 18;
+    const double* M = A.trec + (int64_t)sp * DLR_REC;
+    const double* xm = A.x + 3 * (sp - 1);
+    const double* xs = A.x + 3 * sp;
+    const double* xp = A.x + 3 * (sp + 1);
+    const int m0 = c == 0 ? 0 : (c == 1 ? 1 : 2), m1 = c == 0 ? 1 : (c == 1 ? 3 : 4), m2 = c == 0 ? 2 : (c == 1 ? 4 : 5);
+    double g = M[m0] * xs[0] + M[m1] * xs[1] + M[m2] * xs[2];
+    for (int k = 0; k < 3; ++k) g -= ks[3 * c + k] * xm[k] + ks[9 + 3 * k + c] * xp[k];
+    sg[s] = g;
+  }
+  __syncthreads();
+  if (s < A.nU) {
+    double w = 0.0;
+    for (int v = 0; v < A.nU; ++v) w += A.Sinv[s * A.nU + v] * sg[v];
+    sw[s] = w;
+  }
+  __syncthreads();
+  for (int i = i0; i < i1; ++i) {
+    int su = -1;
+    for (int q = 0; q < A.nsep; ++q)
+      if (i == A.sep[q]) su = 3 * q;
+    for (int c = 0; c < 3; ++c) {
+      const int r = 3 * i + c;
+      if (su >= 0) {
+        A.x[r] = sw[su + c];
+      } else {
+        const double* y = A.Y + (int64_t)r * A.yld;
+        double acc = 0.0;
+        for (int u = 0; u < A.nU; ++u) acc += y[u] * sw[u];
+        A.x[r] -= acc;
       }
     }
   }

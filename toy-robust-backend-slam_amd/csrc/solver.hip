@@ -177,6 +177,8 @@ struct pgo_handle {
   double *dl_trec = nullptr, *dl_fac = nullptr, *dl_pre = nullptr, *dl_vrec = nullptr, *dl_Z = nullptr, *dl_cap = nullptr, *dl_dwork = nullptr,
          *dl_nm = nullptr, *dl_cy = nullptr, *dl_cvec = nullptr, *dl_x1 = nullptr, *dl_E = nullptr, *dl_E2 = nullptr;
   int dl_nseg = 1, dl_seglen = 1;
+  int dl_nseg2 = 1, dl_seglen2 = 1;   // the finer segmentation of k_dlr_solve1 (up to 256 segments of <= 16 poses)
+  double* dl_pre2 = nullptr;
   int dl_nsep = 0, dl_sep[dev::DLR_MAX_SEP] = {0}, dl_nU = 0;
   double *dl_ksep = nullptr, *dl_R = nullptr, *dl_Wm = nullptr;
   double dl_rel = 0.0;  // |g - (H + D'D) y| / |g| of the latest direct solve
@@ -1104,6 +1106,11 @@ int pgo_handle::direct_setup(int32_t N, bool switch_now) {
   if (const char* ns = getenv("PGO_DIRECT_NSEG")) want_seg = std::min(dev::DLR_MAX_SEG, std::max(1, atoi(ns)));
   dl_seglen = std::max(1, (N + want_seg - 1) / want_seg);
   dl_nseg = (N + dl_seglen - 1) / dl_seglen;
+  if (N <= 4096 && !getenv("PGO_DIRECT_NO_SOLVE1")) {
+    dl_seglen2 = std::max(1, (N + 255) / 256);
+    dl_nseg2 = (N + dl_seglen2 - 1) / dl_seglen2;
+    PGOC(dalloc(&dl_pre2, (int64_t)dev::DLR_PRE * N));
+  }
   PGOC(dalloc(&dl_E, (int64_t)dl_nseg * 3 * dl_ld));
   PGOC(dalloc(&dl_E2, (int64_t)dl_nseg * 3 * dl_ld));
   HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_chol_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::CHOL_LDS_BYTES));
@@ -1156,6 +1163,11 @@ int pgo_handle::direct_enqueue() {
   PGOC(check_launch("k_dlr_factor"));
   hipLaunchKernelGGL(dev::k_dlr_prefix, dim3(1), dim3(128), 0, stream, (const double*)dl_fac, n, dl_nseg, dl_seglen, dl_pre);
   PGOC(check_launch("k_dlr_prefix"));
+  const bool one_launch = dl_refine > 0 && dl_pre2 != nullptr;   // the refinement's single column: k_dlr_solve1
+  if (one_launch) {
+    hipLaunchKernelGGL(dev::k_dlr_prefix, dim3(1), dim3(512), 0, stream, (const double*)dl_fac, n, dl_nseg2, dl_seglen2, dl_pre2);
+    PGOC(check_launch("k_dlr_prefix (fine segments)"));
+  }
   dev::DlrColsArgs C;
   C.fac = dl_fac;
   C.pre = dl_pre;
@@ -1238,21 +1250,45 @@ int pgo_handle::direct_enqueue() {
   };
   for (int it = 0; it < dl_refine; ++it) {
     PGOC(residual_product());
-    dev::DlrColsArgs C1 = C;
-    C1.ncols = 1;
-    C1.K = 0;
-    C1.vec_col = 0;
-    C1.ld = 64;
-    C1.rhs_sub = ap;
-    C1.X = dl_x1;
-    C1.nsep = 0;   // (no U columns: Y and R of the main solve are reused)
-    PGOC(solve_columns(C1));
-    PGOC(separator_fix(dl_x1, 64, 1));
-    hipLaunchKernelGGL(dev::k_dlr_vdot, dim3((Kp + 255) / 256), dim3(256), 0, stream, A, (const double*)dl_x1, 64, 0, dl_cvec);
+    int xld = 64;   // layout of the single column in dl_x1: [3n][64] (batched kernels) or a plain vector (k_dlr_solve1)
+    if (one_launch) {
+      dev::DlrSolve1Args Q;
+      Q.fac = dl_fac;
+      Q.pre2 = dl_pre2;
+      Q.n = n;
+      Q.nseg = dl_nseg2;
+      Q.seglen = dl_seglen2;
+      Q.rhs_b = gs;
+      Q.rhs_sub = ap;
+      Q.x = dl_x1;
+      Q.nsep = dl_nsep;
+      Q.nU = dl_nU;
+      for (int j = 0; j < dev::DLR_MAX_SEP; ++j) Q.sep[j] = dl_sep[j];
+      Q.ksep = dl_ksep;
+      Q.trec = dl_trec;
+      Q.Y = dl_Z + (K + 1);
+      Q.yld = dl_ld;
+      Q.Sinv = dl_R;
+      hipLaunchKernelGGL(dev::k_dlr_solve1, dim3(1), dim3(256), 0, stream, Q);
+      PGOC(check_launch("k_dlr_solve1"));
+      xld = 1;
+    } else {
+      dev::DlrColsArgs C1 = C;
+      C1.ncols = 1;
+      C1.K = 0;
+      C1.vec_col = 0;
+      C1.ld = 64;
+      C1.rhs_sub = ap;
+      C1.X = dl_x1;
+      C1.nsep = 0;   // (no U columns: Y and R of the main solve are reused)
+      PGOC(solve_columns(C1));
+      PGOC(separator_fix(dl_x1, 64, 1));
+    }
+    hipLaunchKernelGGL(dev::k_dlr_vdot, dim3((Kp + 255) / 256), dim3(256), 0, stream, A, (const double*)dl_x1, xld, 0, dl_cvec);
     PGOC(check_launch("k_dlr_vdot"));
     PGOC(capacitance_solve());
     hipLaunchKernelGGL(dev::k_dlr_combine, dim3((3 * n + 3) / 4), dim3(256), 0, stream, (const double*)dl_Z, dl_ld, K, (const double*)dl_cvec,
-                       (const double*)dl_x1, 64, 0, 3 * n, y, 1);
+                       (const double*)dl_x1, xld, 0, 3 * n, y, 1);
     PGOC(check_launch("k_dlr_combine"));
   }
   PGOC(residual_product());
