@@ -73,7 +73,10 @@ def main():
                          "after the number of slices the previous solve makes likely, then after every slice")
     ap.add_argument("--pcg-chain-len", type=int, default=-1,
                     help="chain (block-tridiagonal) preconditioner over segments of this many poses, 0 = off, -1 = auto (GPU and CPU baseline)")
-    ap.add_argument("--halo-exchange", type=int, default=1, help="N > 1: 1 = point-to-point halo exchange of the search direction, 0 = all-gather")
+    ap.add_argument("--halo-exchange", type=int, default=-1,
+                    help="N > 1: 1 = point-to-point halo exchange of the search direction, 0 = all-gather, -1 (default) = the p2p "
+                         "exchange if a check against the all-gather on the first LM iterations agrees, else the all-gather")
+    ap.add_argument("--pose-ordering", type=int, default=-1, help="internal locality ordering of the poses: 0 off, 1 on, -1 = the library's rule")
     ap.add_argument("--halo-overlap", type=int, default=0, help="N > 1: 1 = exchange on a second stream behind the owned-column SpMV")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--cpu-iters", type=int, default=8,
@@ -133,10 +136,37 @@ def main():
     g = P.synth_manhattan(args.poses, 4.0, 0.10, 20260410)
     t_gen = time.time() - t_gen
     K, W = args.steps, args.warmup
-    opt = P.Options(method=1, max_iters=W + K, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0, pcg_rtol=args.pcg_rtol,
+
+    def options(**kw):
+        base = dict(method=1, max_iters=W + K, ftol=0.0, gtol=0.0, ptol=0.0, min_radius=0.0, pcg_rtol=args.pcg_rtol,
                     pcg_max_iters=args.pcg_max_iters, pcg_block_poses=args.pcg_block_poses, pcg_chain_len=args.pcg_chain_len,
-                    halo_exchange=args.halo_exchange, halo_overlap=args.halo_overlap,
+                    halo_exchange=max(0, args.halo_exchange), halo_overlap=args.halo_overlap, pose_ordering=args.pose_ordering,
                     pcg_check_every=min(max(1, args.pcg_check_every), max(1, args.pcg_max_iters)), verbose=args.verbose if rank == 0 else 0)
+        base.update(kw)
+        return P.Options(**base)
+
+    # Several ranks: the point-to-point halo exchange moves far fewer bytes than the all-gather, but the library keeps the
+    # all-gather as its default until the p2p path has been checked against it on real peers -- so that check runs HERE,
+    # on the first LM iterations of this workload, and the p2p path is timed only if every rank saw the same result.
+    halo_check = None
+    halo = max(0, args.halo_exchange)
+    if world > 1 and args.halo_exchange < 0:
+        res = []
+        for hx in (0, 1):
+            try:
+                sc = P.Solver(g, options(max_iters=2, halo_exchange=hx, halo_overlap=0, verbose=0), comm, device=local_rank)
+                smc = sc.solve()
+                res.append((smc.final_cost, smc.total_pcg_iters, [r["step_ok"] for r in sc.iter_records()]))
+                sc.close()
+            except P.PgoError as e:
+                res.append(("error", repr(e)))
+        same = (len(res) == 2 and res[0][0] != "error" and res[1][0] != "error" and res[0][1:] == res[1][1:]
+                and abs(res[0][0] - res[1][0]) <= 1e-12 * abs(res[0][0]))
+        flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        halo = 1 if float(flag.cpu()[0]) > 0.5 else 0
+        halo_check = {"all_gather": res[0], "p2p": res[1], "agree_on_every_rank": bool(halo), "timed": "p2p halo exchange" if halo else "all-gather"}
+    opt = options(halo_exchange=halo)
     t_create = time.time()
     s = P.Solver(g, opt, comm, device=local_rank)
     t_create = time.time() - t_create
@@ -259,7 +289,8 @@ def main():
             "seconds": {"generate": t_gen, "create": t_create, "eval": summ.seconds_eval,
                         "assemble": summ.seconds_assemble, "linear": summ.seconds_linear,
                         "candidate": summ.seconds_candidate},
-            "handle": {k: v for k, v in s.info().as_dict().items() if k in ("pcg_block_poses", "pcg_chain_len", "chain_kernel", "n_tiles",
+            "halo_exchange_check": halo_check,
+            "handle": {k: v for k, v in s.info().as_dict().items() if k in ("pcg_block_poses", "pcg_chain_len", "chain_kernel", "n_tiles", "pose_ordering",
                                                                            "n_incidences", "halo_send_rows", "halo_recv_rows", "device_bytes",
                                                                            "host_enqueue_us_per_pcg_iter", "pcg_graph_replay")},
         }

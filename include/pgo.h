@@ -151,9 +151,13 @@ typedef struct pgo_options {
                                   0 = auto (32 for graphs of <= 8192 poses, which are launch-latency bound and
                                   chain-like, else 4) */
   int32_t halo_exchange;       /* world > 1: how the search direction reaches the other ranks each PCG iteration.
-                                  1 (default) = point-to-point halo exchange: every rank sends each peer only the rows that
-                                      peer's off-diagonal blocks reference (one ncclSend/ncclRecv group on the solver's stream);
-                                  0 = in-place all-gather of all 3N doubles                                       */
+                                  0 (default) = in-place all-gather of all 3N doubles (exercised through RCCL, captured into
+                                      the PCG hipGraph);
+                                  1 (opt-in) = point-to-point halo exchange: every rank sends each peer only the rows that
+                                      peer's off-diagonal blocks reference (one ncclSend/ncclRecv group on the solver's stream).
+                                      Far fewer bytes, but the RCCL send/recv group has not yet run against a real peer:
+                                      bench.py checks it against the all-gather result when it runs on several GPUs and
+                                      times it only if the two agree                                                  */
   double  sc_prior_lambda;     /* 1.0  METHOD 2: weight of the switch prior sqrt(lambda)(1 - s)  (main.cpp:107)    */
   int32_t pose_ordering;       /* internal numbering of the poses (results are always in the caller's numbering):
                                   0 = the caller's, 1 = locality ordering (pgo_pose_order: segments of 64 consecutive
@@ -375,6 +379,19 @@ int pgo_debug_spmv(pgo_t* h, const double* x, double* y);                       
 /* normal-equation pieces at the current point, caller's pose order (world == 1):
  * g: 3N gradient J'r (unscaled), hdiag: N x 9 diagonal 3x3 blocks of J'J         */
 int pgo_debug_normal_eq(pgo_t* h, double* g_or_null, double* hdiag_or_null);      /* [gpu] */
+/* Test hooks -- for tests/ only, not part of the drop-in surface.  Process-wide knobs read by pgo_create* (handles
+ * created afterwards); value < 0 restores the library's default.  The library reads NO environment variable other than
+ * PGO_FORCE_COLLECTIVES (1 = issue the collectives at world == 1 too, where they are identities) and
+ * PGO_GRAPH_COLLECTIVES (0 = never capture collectives into the PCG hipGraph, 1 = all-reduce / all-gather, 2 = also the
+ * point-to-point exchange), and never lets the environment override a pgo_options field.
+ *   "spmv_pipe"          0 = K3 as k_spmv_t instead of the software-pipelined k_spmv_p (the two must agree)
+ *   "fused_p"            0 = small graphs keep the three-launch PCG loop (no direction update inside the SpMV)
+ *   "direct_fail_at"     k = the direct solve of LM iteration k returns NaNs (exercises the PCG redo)
+ *   "direct_setup_fail"  1 = setting up the direct solver fails with PGO_ERR_NOMEM after its first allocations
+ *   "single_reduction"   1 / 0 = force the one-reduction (Chronopoulos-Gear) PCG loop on / off (default: on for
+ *                        world > 1 in the inexact mode, pcg_rtol >= 1e-6)
+ * Unknown name: PGO_ERR_INVALID_ARG.                                                                              */
+int pgo_debug_set_knob(const char* name, long long value);                        /* [host] */
 /* sharding plan of a graph over `world` ranks: for rank r, rows [lo, hi) and the
  * number of local edges / cut edges.  rows per rank = ceil(N / world) rounded up to a
  * multiple of row_align (the solver passes its preconditioner block size, see

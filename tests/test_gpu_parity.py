@@ -312,15 +312,58 @@ def test_auto_changes_to_the_direct_solve_when_pcg_is_expensive(pgo):
         s.close()
 
 
-def test_direct_solve_failure_falls_back_to_pcg(pgo, monkeypatch):
+def test_direct_setup_failure_keeps_the_solve_on_pcg(pgo):
+    """auto mode above rank 2048 sets the direct solver up in the MIDDLE of a solve (about 1 GB of buffers at rank 5862): if
+    that fails (here through the test hook, as a hipMalloc failure would) the solve goes on with PCG -- a heuristic speed-up
+    never becomes a failed pgo_solve -- the partial buffers are freed and the handle does not try again"""
+    g = load(pgo, "M3500")
+    ref = pgo.Solver(g, pgo.Options(method=1, linear_solver=1, pcg_max_iters=400000, max_iters=8))
+    sr = ref.solve()
+    pgo.set_knob("direct_setup_fail", 1)
+    try:
+        s = pgo.Solver(g, pgo.Options(method=1, pcg_max_iters=400000, max_iters=8))
+        bytes0 = s.info().device_bytes
+        sm = s.solve()
+    finally:
+        pgo.set_knob("direct_setup_fail", -1)
+    i = s.info()
+    assert i.linear_solver == 1 and i.direct_switched_at == 0 and i.device_bytes == bytes0
+    assert all(r["pcg_iters"] > 0 for r in s.iter_records()[1:])
+    assert sm.iterations == sr.iterations and sm.final_cost == pytest.approx(sr.final_cost, rel=1e-9)
+    np.testing.assert_allclose(s.poses(), ref.poses(), atol=1e-7)
+    assert pgo.lib().pgo_last_error() in (b"", None)
+    s.set_poses(np.array(g.poses))       # the handle stays usable and stays on PCG
+    assert s.solve().final_cost == pytest.approx(sr.final_cost, rel=1e-9) and s.info().linear_solver == 1
+    s.close(); ref.close()
+
+
+def test_preconditioner_entry_points_on_a_direct_solve_handle(pgo):
+    """a handle on the direct solve (INTEL, default options) does not factorise the PCG preconditioner per LM iteration;
+    pgo_debug_precond / pgo_bench_precond set it up themselves instead of applying stale factors"""
+    s = pgo.Solver(load(pgo, "INTEL", 50), pgo.Options(method=1, max_iters=3))
+    s.solve()
+    assert s.info().linear_solver == 2
+    rng = np.random.default_rng(5)
+    n = 3 * s.info().n_poses
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+    Mu, Mv = s.precond(u), s.precond(v)
+    assert np.isfinite(Mu).all() and float(u @ Mu) > 0.0 and float(v @ Mv) > 0.0 and np.abs(Mu[3:]).max() > 0.0
+    assert float(u @ Mv) == pytest.approx(float(v @ Mu), rel=1e-9)
+    assert s.bench_precond(3).ms_avg > 0.0
+    s.close()
+
+
+def test_direct_solve_failure_falls_back_to_pcg(pgo):
     """a direct solve that yields no usable step (here: poisoned with NaNs at LM iteration 3 through the test hook) is redone
     by PCG inside the same LM iteration: the trajectory still reaches the golden fixture"""
     tag = "INTEL_out50_m1"
     fx = json.load(open(os.path.join(GOLDEN, "lm_%s.json" % tag)))
     ref = np.load(os.path.join(GOLDEN, "lm_%s_poses.npy" % tag))
-    monkeypatch.setenv("PGO_DIRECT_FAIL_AT", "3")
-    s = pgo.Solver(load(pgo, "INTEL", 50), pgo.Options(method=1))
-    monkeypatch.delenv("PGO_DIRECT_FAIL_AT")
+    pgo.set_knob("direct_fail_at", 3)
+    try:
+        s = pgo.Solver(load(pgo, "INTEL", 50), pgo.Options(method=1))
+    finally:
+        pgo.set_knob("direct_fail_at", -1)
     summ = s.solve()
     recs = s.iter_records()
     assert s.info().linear_solver == 2 and s.info().direct_fallbacks == 1
@@ -417,32 +460,36 @@ def test_direct_solve_other_options_and_reproducibility(pgo, oracle):
     s.close()
 
 
-def test_product_kernels_agree(pgo, oracle, monkeypatch):
+def test_product_kernels_agree(pgo, oracle):
     """K3 has two product kernels -- the software-pipelined k_spmv_p (plain tiles) and k_spmv_t (every other case) -- and
     small graphs take the fused-direction-update loop (k_spmv_t MODE 5): the same product / the same solve from each"""
     g = pgo.synth_manhattan(60000, 4.0, 0.10, 3)
     x = np.random.default_rng(9).standard_normal(3 * g.n_poses)
     ys = {}
     for pipe in ("1", "0"):
-        monkeypatch.setenv("PGO_SPMV_PIPE", pipe)
-        s = pgo.Solver(g, pgo.Options(method=1, max_iters=2, pcg_rtol=0.1, pcg_max_iters=100))
+        pgo.set_knob("spmv_pipe", int(pipe))
+        try:
+            s = pgo.Solver(g, pgo.Options(method=1, max_iters=2, pcg_rtol=0.1, pcg_max_iters=100))
+        finally:
+            pgo.set_knob("spmv_pipe", -1)
         s.lm_begin()
         s.lm_step(1)
         ys[pipe] = s.spmv(x)
         s.close()
-    monkeypatch.delenv("PGO_SPMV_PIPE")
     assert np.abs(ys["1"] - ys["0"]).max() < 1e-11 * np.abs(ys["0"]).max()
     og = oracle_graph(oracle, g)
     # the fused loop against the three-kernel loop on a small graph: same iterates up to rounding
     gi = load(pgo, "INTEL", 50)
     out = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("PGO_FUSED_P", fused)
-        s = pgo.Solver(gi, pgo.Options(method=1, max_iters=6, linear_solver=1))
+        pgo.set_knob("fused_p", int(fused))
+        try:
+            s = pgo.Solver(gi, pgo.Options(method=1, max_iters=6, linear_solver=1))
+        finally:
+            pgo.set_knob("fused_p", -1)
         sm = s.solve()
         out[fused] = (s.poses(), sm.total_pcg_iters, sm.final_cost)
         s.close()
-    monkeypatch.delenv("PGO_FUSED_P")
     assert out["1"][2] == pytest.approx(out["0"][2], rel=1e-10)
     assert abs(out["1"][1] - out["0"][1]) <= 6          # PCG iterations over 6 LM iterations
     assert np.abs(out["1"][0] - out["0"][0]).max() < 1e-8

@@ -21,7 +21,7 @@ import numpy as np
 from . import _build
 
 __all__ = ["PgoError", "Options", "Summary", "IterRecord", "ReadG2O", "Graph", "Solver", "Batch", "Comm", "lib", "build",
-           "HandleInfo", "synth_manhattan", "solve_batch", "shard_plan", "shard_halo", "pose_order", "KernelStats", "EXPORTS", "TERMINATION"]
+           "HandleInfo", "synth_manhattan", "solve_batch", "shard_plan", "shard_halo", "pose_order", "set_knob", "KernelStats", "EXPORTS", "TERMINATION"]
 
 EDGE_ODOMETRY, EDGE_CLOSURE, EDGE_BOGUS = 0, 1, 2
 TERMINATION = {1: "CONVERGENCE_FTOL", 2: "CONVERGENCE_GTOL", 3: "CONVERGENCE_PTOL", 4: "NO_CONVERGENCE",
@@ -42,6 +42,7 @@ EXPORTS = [
     "pgo_num_iter_records", "pgo_get_iter_records", "pgo_get_info", "pgo_get_poses", "pgo_set_poses", "pgo_get_switches",
     "pgo_write_switches",
     "pgo_bench_eval", "pgo_bench_assemble", "pgo_bench_spmv", "pgo_bench_precond", "pgo_debug_precond", "pgo_debug_spmv", "pgo_debug_normal_eq",
+    "pgo_debug_set_knob",
     "pgo_shard_plan", "pgo_shard_halo", "pgo_pose_order",
 ]
 
@@ -210,6 +211,7 @@ def lib():
     L.pgo_shard_halo.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int64)]
     L.pgo_pose_order.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int32, ip]
+    L.pgo_debug_set_knob.argtypes = [C.c_char_p, C.c_longlong]
     _LIB = L
     return L
 
@@ -366,6 +368,11 @@ def shard_plan(n_poses, ia, ib, world, rank, row_align=1):
     _check(lib().pgo_shard_plan(n_poses, len(ia), _ip(ia), _ip(ib), world, rank, row_align, C.byref(lo), C.byref(hi),
                                 C.byref(nl), C.byref(nc)))
     return lo.value, hi.value, nl.value, nc.value
+
+
+def set_knob(name: str, value: int = -1):
+    """test hook (pgo_debug_set_knob): process-wide, read when a handle is created; value < 0 = library default"""
+    _check(lib().pgo_debug_set_knob(name.encode(), int(value)))
 
 
 def pose_order(n_poses, ia, ib, segment=64):

@@ -124,8 +124,9 @@ __device__ __forceinline__ void hoff_store(double* __restrict__ hoff, int64_t q,
 }
 // a pose's three doubles of the gathered vector: one 16-byte + one 8-byte load (the vector is 8-byte aligned only)
 typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+template <int STRIDE = PS>
 __device__ __forceinline__ void gather3(const double* __restrict__ p, int64_t col, double& p0, double& p1, double& p2) {
-  const double* q = p + PS * col;
+  const double* q = p + STRIDE * col;
   const double2_a8 t = *reinterpret_cast<const double2_a8*>(q);
   p0 = t.x;
   p1 = t.y;
@@ -636,7 +637,8 @@ struct CgState {       // lives in device memory
   int32_t done;
   int32_t iters;
   int32_t pending;     // fused-update loop (k_spmv MODE 5): an iteration's r.z / r.r partials wait to be booked
-  int32_t _pad;
+  int32_t started;     // fused-update loop: 0 until the first k_cg_update1 of the solve has run.  Written by k_cg_init_fin and
+                       // k_cg_update1* only -- never during a k_spmv launch, whose workgroups all read it
 };
 
 struct SpmvArgs {
@@ -721,7 +723,9 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
       A.st->pending = 0;
       if (rr <= tol2) A.st->done = 1;
     }
-    if (rr <= tol2 && A.st->iters + A.st->pending > 0) return;  // converged (same decision everywhere; never before iteration 1)
+    // converged (same decision everywhere; never in the first product of a solve, whose partials are stale).  `started`
+    // is not written during this launch -- iters / pending are, by workgroup 0 above
+    if (rr <= tol2 && A.st->started) return;
     beta = rz_new / rz_old;
   }
   for (; t < xr.end; t += xr.step) {
@@ -863,6 +867,10 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
 // tile t + 1 -- block stream, gathers, row operands -- issued BEFORE the barrier and the row phase of tile t, so that a
 // workgroup always has a tile's worth of memory requests in flight instead of waiting out one round trip per tile.
 // Costs registers (two tiles' operands live: ~110 VGPRs, 4 workgroups per CU instead of 8) -- the same bytes in flight.
+// PSTR: doubles per pose of the gathered vector.  PS in the product; experiment builds (scripts/exp_mall.sh) time the kernel
+// on a copy of p spread over 96 / 288 bytes per pose -- a table of 96 / 288 MB at 1M poses, i.e. inside / beyond the
+// 256 MiB Infinity Cache -- to tell gathers served by that cache from gathers served by HBM.
+template <int PSTR = PS>
 __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
   __shared__ double scr[2][3][WG];
   __shared__ double red[8];
@@ -893,14 +901,14 @@ __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
       L.h1 = ld_stream(A.hd + ((int64_t)i1 * n + L.row));
       L.h2 = ld_stream(A.hd + ((int64_t)i2 * n + L.row));
       if (A.with_d2) L.dd = ld_stream(A.d2 + (3 * (int64_t)L.row + a));
-      gather3(A.p, (int64_t)A.lo + L.row, L.pr0, L.pr1, L.pr2);
+      gather3<PSTR>(A.p, (int64_t)A.lo + L.row, L.pr0, L.pr1, L.pr2);
     }
     L.on = tid < nq;
     L.p0 = L.p1 = L.p2 = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) L.h[c] = 0.0;
     if (L.on) {
-      gather3(A.p, (int64_t)col_, L.p0, L.p1, L.p2);
+      gather3<PSTR>(A.p, (int64_t)col_, L.p0, L.p1, L.p2);
       if (A.nt) hoff_load_nt(A.hoff, q0 + tid, L.h);
       else hoff_load(A.hoff, q0 + tid, L.h);
     }
@@ -1168,6 +1176,7 @@ __global__ void k_cg_init_fin(CgState* st, const double* __restrict__ scal, doub
     st->done = (scal[1] == 0.0) ? 1 : 0;
     st->iters = 0;
     st->pending = 0;
+    st->started = 0;
   }
 }
 
@@ -1207,7 +1216,10 @@ __global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, const do
     part_rz[blockIdx.x] = rz;
     part_rr[blockIdx.x] = rr;
   }
-  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) V.st->pending = 1;
+  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) {
+    V.st->pending = 1;
+    V.st->started = 1;
+  }
 }
 
 // End of a slice of fused-update iterations (k_spmv MODE 5): book the last iteration's partials so that the host sees
@@ -1449,7 +1461,10 @@ __global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int pa
     part_rz[blockIdx.x] = rz;
     part_rr[blockIdx.x] = rr;
   }
-  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) V.st->pending = 1;
+  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) {
+    V.st->pending = 1;
+    V.st->started = 1;
+  }
 }
 
 // ------------------------------------------------- chain (block-tridiagonal) preconditioner
@@ -1882,7 +1897,10 @@ __global__ __launch_bounds__(WG) void k_cg_update1_c(CgVec V, ChainPre C, int pa
     part_rz[blockIdx.x] = rz;
     part_rr[blockIdx.x] = rr;
   }
-  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) V.st->pending = 1;
+  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) {
+    V.st->pending = 1;
+    V.st->started = 1;
+  }
 }
 
 // ------------------------------------------------- chain preconditioner, lean apply (segments of <= 64 * CH rows)
@@ -2280,7 +2298,10 @@ __global__ __launch_bounds__(64 * NW) void k_cg_update1_cl(CgVec V, ChainPre C, 
     part_rz[blockIdx.x] = rz;
     part_rr[blockIdx.x] = rr;
   }
-  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) V.st->pending = 1;
+  if (V.fused && blockIdx.x == 0 && threadIdx.x == 0) {
+    V.st->pending = 1;
+    V.st->started = 1;
+  }
   PGO_T(6);
 }
 

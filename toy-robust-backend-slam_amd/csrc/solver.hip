@@ -45,6 +45,29 @@ namespace dev = pgo::dev;
     if (_s != PGO_OK) return _s; \
   } while (0)
 
+// Experiment switches (scripts/exp_*.sh build a library of their own with -DPGO_EXPERIMENTS and select it with PGO_LIB):
+// the product library reads two documented environment variables only -- PGO_FORCE_COLLECTIVES, PGO_GRAPH_COLLECTIVES --
+// and never lets the environment override a pgo_options field.
+#ifdef PGO_EXPERIMENTS
+#define PGO_EXP_ENV(name) getenv(name)
+#else
+#define PGO_EXP_ENV(name) ((const char*)nullptr)
+#endif
+
+// Test hooks (pgo_debug_set_knob, include/pgo.h): process-wide, read when a handle is created.  -1 = library default.
+namespace {
+struct Knob {
+  const char* name;
+  std::atomic<long long> value;
+};
+Knob g_knobs[] = {{"spmv_pipe", {-1}}, {"fused_p", {-1}}, {"direct_fail_at", {-1}}, {"direct_setup_fail", {-1}}, {"single_reduction", {-1}}};
+long long knob(const char* name) {
+  for (Knob& k : g_knobs)
+    if (!strcmp(k.name, name)) return k.value.load();
+  return -1;
+}
+}  // namespace
+
 static double wall_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -184,12 +207,18 @@ struct pgo_handle {
   double dl_rel = 0.0;  // |g - (H + D'D) y| / |g| of the latest direct solve
   bool dl_retry = false;   // the current LM iteration is being redone by PCG after a failed direct solve
   int dl_fallbacks = 0;    // how often that happened
-  int dl_fail_at = 0;      // PGO_DIRECT_FAIL_AT (tests): poison the direct solve of this LM iteration
+  int dl_fail_at = 0;      // test hook (pgo_debug_set_knob "direct_fail_at"): poison the direct solve of this LM iteration
   bool dl_possible = false;     // auto, rank above DIRECT_AUTO_RANK: the direct solve can take over from PCG (lm_iteration)
   double dl_est_seconds = 0.0;  // what a direct solve of this rank costs (model fitted to INTEL / FRH / M3500)
   int dl_switched_at = 0;       // LM iteration after which it first did
   int dl_last_probe = 0, dl_dear_run = 0;
   bool dl_ready = false;        // the direct solve's buffers exist
+  void clear_direct_buffers() {   // after a failed direct_setup(): every pointer it may have set (the memory is freed by the caller)
+    dl_chain_edge = dl_lr_edge = dl_va = dl_vb = nullptr;
+    dl_trec = dl_fac = dl_pre = dl_vrec = dl_Z = dl_cap = dl_dwork = dl_nm = dl_cy = dl_cvec = dl_x1 = dl_E = dl_E2 = nullptr;
+    dl_pre2 = dl_ksep = dl_R = dl_Wm = nullptr;
+    dl_ready = false;
+  }
   hipGraphExec_t dl_graph_exec = nullptr;   // the captured direct solve
   bool dl_graph_failed = false;
   bool dl_use_graph = false;   // PGO_DIRECT_GRAPH=1
@@ -423,11 +452,13 @@ struct pgo_handle {
   int spmv_enqueue(const double* p, double* yout, double* dot_part, int with_d2, const int32_t* done) {
     dev::SpmvArgs A = spmv_args(p, yout, dot_part, with_d2, done);
     switch (spmv_ablate) {
+#ifdef PGO_EXPERIMENTS
       case 1: hipLaunchKernelGGL(dev::k_spmv_t<1>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
       case 2: hipLaunchKernelGGL(dev::k_spmv_t<2>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
       case 3: hipLaunchKernelGGL(dev::k_spmv_t<3>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
+#endif
       default:
-        if (spmv_pipe) hipLaunchKernelGGL(dev::k_spmv_p, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+        if (spmv_pipe) hipLaunchKernelGGL(dev::k_spmv_p<dev::PS>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
         else hipLaunchKernelGGL(dev::k_spmv_t<0>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
     }
     return check_launch("k_spmv");
@@ -571,7 +602,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   }
   const char* fc = getenv("PGO_FORCE_COLLECTIVES");
   force_collectives = fc && fc[0] == '1';
-  if (const char* nt = getenv("PGO_SPMV_NT")) spmv_nt = atoi(nt);
+  if (const char* nt = PGO_EXP_ENV("PGO_SPMV_NT")) spmv_nt = atoi(nt);
   if (const char* gc = getenv("PGO_GRAPH_COLLECTIVES")) graph_collectives = atoi(gc);
   grp_B = pgo::resolve_block_poses(opt.pcg_block_poses, N);
   chain_len = pgo::resolve_chain_len(opt.pcg_chain_len, opt.pcg_block_poses, N, E, ia, ib);
@@ -652,7 +683,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   g_rows = std::max(1, cdiv(NL, dev::WG));
   g_vec = std::min(std::max(1, cdiv(NL, dev::WG)), 1024);
   g_flat = std::min(std::max(1, cdiv(3 * NL, dev::WG)), 1024);
-  if (const char* fe = getenv("PGO_FLAT_GRID")) g_flat = std::min(g_flat, std::max(8, atoi(fe)));
+  if (const char* fe = PGO_EXP_ENV("PGO_FLAT_GRID")) g_flat = std::min(g_flat, std::max(8, atoi(fe)));
   g_spmv = up8(std::min(std::max(1, S.n_tiles()), 2048));
   g_asm = up8(std::min(std::max(1, S.n_tiles()), 1 << 20));
   part_cap = std::max(g_edge, 2048) + 8;
@@ -681,7 +712,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     // in breadth-first order of the tile graph (compute_tile_order): tiles running together gather the same lines
     std::vector<int4> desc((size_t)std::max(1, S.n_tiles()));
     std::vector<int32_t> order;
-    const char* to = getenv("PGO_TILE_ORDER");
+    const char* to = PGO_EXP_ENV("PGO_TILE_ORDER");
     // OFF by default: it cuts the gather traffic (FETCH_SIZE 992 -> 920-937 MB at 1M poses) but the scattered 18-KB
     // H chunks cost more than that saves (184 vs 179 us); PGO_TILE_ORDER=1 turns it on (never in a batch, which keeps
     // each problem's tiles together)
@@ -695,14 +726,13 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       // the software-pipelined product kernel (k_spmv_p) needs plain tiles: no chunked heavy row, at most 85 rows
       // (one row-phase pass); PGO_SPMV_PIPE=0 keeps k_spmv_t.  Measured on one box at 1M poses: k_spmv_t 185.7 us (8
       // workgroups per CU), k_spmv_p 172.4 / 175.5 / 168.8 / 165.1 us at 8 / 6 / 5 / 4 workgroups per CU.
-      const char* pe = getenv("PGO_SPMV_PIPE");
-      bool ok = !(pe && pe[0] == '0');
+      bool ok = knob("spmv_pipe") != 0;   // (test hook: 0 keeps k_spmv_t so that the two product kernels can be compared)
       for (int t = 0; ok && t < S.n_tiles(); ++t)
         ok = desc[t].w <= dev::WG && desc[t].y * 3 <= dev::WG;
       spmv_pipe = ok;
       if (ok) {
         int per_cu = 4;
-        if (const char* ge = getenv("PGO_SPMV_PIPE_WGS")) per_cu = std::max(1, atoi(ge));
+        if (const char* ge = PGO_EXP_ENV("PGO_SPMV_PIPE_WGS")) per_cu = std::max(1, atoi(ge));
         g_spmv = ((std::min(std::max(1, S.n_tiles()), 256 * per_cu) + 7) / 8) * 8;
       }
     }
@@ -803,7 +833,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     // <= 64 poses, 4 for longer ones (INTEL, chain-256: 20 us per apply in the scan form -- five 256-row tiles, latency-
     // bound -- of a 30 us PCG iteration); PGO_CHAIN_KERNEL = scan | lean2 | lean4 overrides (experiments)
     chain_chunk = chain_len <= 64 ? 2 : 4;   // 4: segments of up to 256 poses (the small chain-like graphs)
-    if (const char* ck = getenv("PGO_CHAIN_KERNEL")) {
+    if (const char* ck = PGO_EXP_ENV("PGO_CHAIN_KERNEL")) {
       if (!strcmp(ck, "scan")) chain_chunk = 0;
       else if (!strcmp(ck, "lean2") && (128 % chain_len) == 0) chain_chunk = 2;
       else if (!strcmp(ck, "lean4")) chain_chunk = 4;
@@ -816,20 +846,20 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       // segments: 7.4 -> 4.8 us per apply); large graphs keep the 4-wave workgroups and the serial DPP recurrence,
       // which needs fewer registers and no LDS-crossbar shuffles.
       int64_t small_max = 512;
-      if (const char* sm = getenv("PGO_CHAIN_SMALL_TILES")) small_max = atoll(sm);
+      if (const char* sm = PGO_EXP_ENV("PGO_CHAIN_SMALL_TILES")) small_max = atoll(sm);
       const bool small = n_wt <= small_max;
       chain_nw = small ? 1 : 4;
       chain_scan = 0;
       if (small && chain_len / chain_chunk > 16)
         for (int l = 1; l < chain_len / chain_chunk; l <<= 1) ++chain_scan;
-      if (const char* cs = getenv("PGO_CHAIN_SCAN")) {  // experiments: 0 = always serial
+      if (const char* cs = PGO_EXP_ENV("PGO_CHAIN_SCAN")) {  // experiments: 0 = always serial
         if (atoi(cs) == 0) chain_scan = 0;
       }
       // every workgroup of the NEXT kernel re-sums this kernel's per-workgroup partials, so fewer, longer-running
       // workgroups are cheaper all round: 2048 -> 512 (and 1024 for the flat vector kernels) 25.43 -> 24.65 ms per LM
       // iteration at 1M poses (same box, 3 interleaved repetitions)
       int cap = 512;
-      if (const char* ce = getenv("PGO_CHAIN_GRID")) cap = std::max(8, atoi(ce));
+      if (const char* ce = PGO_EXP_ENV("PGO_CHAIN_GRID")) cap = std::max(8, atoi(ce));
       g_chain = (int)std::min<int64_t>((n_wt + chain_nw - 1) / chain_nw, chain_nw == 1 ? 2048 : cap);
     }
   } else {
@@ -837,7 +867,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   }
   // One-workgroup PCG (solo.hip.h): a single rank, a chain or 3x3 block-Jacobi preconditioner, no chunked heavy row.
   {
-    const char* se = getenv("PGO_SOLO");
+    const char* se = PGO_EXP_ENV("PGO_SOLO");
     // a single graph takes this path only on request (PGO_SOLO=1): one CU's L1 paces the solve -- INTEL 36 us per PCG
     // iteration against 27 us for the three-kernel loop on 256 CUs, MIT / FR079 8 % faster -- the win is the BATCH, where
     // every problem has a CU of its own
@@ -867,10 +897,9 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     solo = ok;
   }
   {
-    const char* fe = getenv("PGO_FUSED_P");
     int64_t fused_max = 16384;
-    if (const char* fm = getenv("PGO_FUSED_MAX_ROWS")) fused_max = atoll(fm);
-    fused_p = !(fe && fe[0] == '0') && world == 1 && !force_collectives && !batch_mode && NL > 0 && NL <= fused_max;
+    if (const char* fm = PGO_EXP_ENV("PGO_FUSED_MAX_ROWS")) fused_max = atoll(fm);
+    fused_p = knob("fused_p") != 0 && world == 1 && !force_collectives && !batch_mode && NL > 0 && NL <= fused_max;
     if (fused_p) PGOC(dalloc(&p_full2, dev::PS * n_full));
   }
   if (!fixed_mask_h.empty()) {
@@ -1016,7 +1045,7 @@ constexpr int DIRECT_AUTO_RANK = 2048;  // auto takes the direct solve up to thi
 int pgo_handle::direct_setup(int32_t N, bool switch_now) {
   const int world = comm ? comm->world : 1;
   int want = switch_now ? 2 : opt.linear_solver;
-  if (const char* de = getenv("PGO_DIRECT")) want = atoi(de) ? 2 : 1;  // experiments: force on / off
+  if (const char* de = PGO_EXP_ENV("PGO_DIRECT")) want = atoi(de) ? 2 : 1;  // experiment builds only: force on / off
   if (want == 1) return PGO_OK;
   if (want != 0 && want != 2) return fail(PGO_ERR_INVALID_ARG, "linear_solver: 0 = auto, 1 = PCG, 2 = direct (chain + low rank)");
   auto no = [&](const std::string& why) -> int {
@@ -1069,21 +1098,21 @@ int pgo_handle::direct_setup(int32_t N, bool switch_now) {
   // 0.3 us per pose); PGO_DIRECT_SEP=0 keeps one piece
   dl_nsep = 0;
   {
-    const char* se = getenv("PGO_DIRECT_SEP");
+    const char* se = PGO_EXP_ENV("PGO_DIRECT_SEP");
     if (N >= 256 && !(se && se[0] == '0')) {
       // 3 separators up to ~5000 poses (INTEL / MIT: 3 -> 826 / 2392 GN it/s, 5 -> 813 / 2294, 7 -> 788 / 2116, 15 -> 606 / 1209:
       // every separator adds 3 columns and a row of the Schur system), then one per ~1200 poses (40k poses: 3 -> 156, 15 -> 205)
       dl_nsep = std::min(dev::DLR_MAX_SEP, std::max(3, (int)(N / 1200)));
-      if (const char* ne = getenv("PGO_DIRECT_NSEP")) dl_nsep = std::min(dev::DLR_MAX_SEP, std::max(1, atoi(ne)));   // experiments
+      if (const char* ne = PGO_EXP_ENV("PGO_DIRECT_NSEP")) dl_nsep = std::min(dev::DLR_MAX_SEP, std::max(1, atoi(ne)));   // experiments
       for (int j = 0; j < dl_nsep; ++j) dl_sep[j] = (int)(((int64_t)(j + 1) * N) / (dl_nsep + 1));
     }
   }
   dl_nU = 3 * dl_nsep;
   dl_ld = ((dl_K + 1 + dl_nU + 63) / 64) * 64;
   dl_refine = 1;   // (a second step does not lower FRH's 5e-8: that residual is what the conditioning allows)
-  if (const char* re = getenv("PGO_DIRECT_REFINE")) dl_refine = std::max(0, atoi(re));
-  if (const char* fa = getenv("PGO_DIRECT_FAIL_AT")) dl_fail_at = atoi(fa);
-  if (const char* ge = getenv("PGO_DIRECT_GRAPH")) dl_use_graph = ge[0] == '1';
+  if (const char* re = PGO_EXP_ENV("PGO_DIRECT_REFINE")) dl_refine = std::max(0, atoi(re));
+  if (knob("direct_fail_at") > 0) dl_fail_at = (int)knob("direct_fail_at");   // test hook
+  if (const char* ge = PGO_EXP_ENV("PGO_DIRECT_GRAPH")) dl_use_graph = ge[0] == '1';
   PGOC(dalloc(&dl_chain_edge, N));
   PGOC(dalloc(&dl_lr_edge, std::max(1, dl_m)));
   PGOC(dalloc(&dl_va, std::max(1, dl_m)));
@@ -1092,6 +1121,7 @@ int pgo_handle::direct_setup(int32_t N, bool switch_now) {
   PGOC(upload(dl_lr_edge, lr));
   PGOC(upload(dl_va, va));
   PGOC(upload(dl_vb, vb));
+  if (knob("direct_setup_fail") > 0) return fail(PGO_ERR_NOMEM, "hipMalloc: out of memory (test hook direct_setup_fail)");
   PGOC(dalloc(&dl_trec, (int64_t)dev::DLR_REC * N));
   PGOC(dalloc(&dl_fac, (int64_t)dev::DLR_REC * (N + 1)));
   PGOC(dalloc(&dl_vrec, (int64_t)dev::DLR_V * std::max(1, dl_m)));
@@ -1103,10 +1133,10 @@ int pgo_handle::direct_setup(int32_t N, bool switch_now) {
   PGOC(dalloc(&dl_cy, dl_Kp));
   PGOC(dalloc(&dl_pre, (int64_t)dev::DLR_PRE * N));
   int want_seg = 32;   // segments the chain sweeps are cut into (PGO_DIRECT_NSEG: experiments, <= 64)
-  if (const char* ns = getenv("PGO_DIRECT_NSEG")) want_seg = std::min(dev::DLR_MAX_SEG, std::max(1, atoi(ns)));
+  if (const char* ns = PGO_EXP_ENV("PGO_DIRECT_NSEG")) want_seg = std::min(dev::DLR_MAX_SEG, std::max(1, atoi(ns)));
   dl_seglen = std::max(1, (N + want_seg - 1) / want_seg);
   dl_nseg = (N + dl_seglen - 1) / dl_seglen;
-  if (N <= 4096 && !getenv("PGO_DIRECT_NO_SOLVE1")) {
+  if (N <= 4096 && !PGO_EXP_ENV("PGO_DIRECT_NO_SOLVE1")) {
     dl_seglen2 = std::max(1, (N + 255) / 256);
     dl_nseg2 = (N + dl_seglen2 - 1) / dl_seglen2;
     PGOC(dalloc(&dl_pre2, (int64_t)dev::DLR_PRE * N));
@@ -1325,7 +1355,7 @@ int pgo_handle::direct_solve() {
     if (dl_graph_exec) HIPC(hipGraphLaunch(dl_graph_exec, stream));
   }
   if (!dl_graph_exec) PGOC(direct_enqueue());
-  if (dl_fail_at > 0 && iter == dl_fail_at)   // test hook (PGO_DIRECT_FAIL_AT): a direct solve that returns NaNs
+  if (dl_fail_at > 0 && iter == dl_fail_at)   // test hook ("direct_fail_at"): a direct solve that returns NaNs
     HIPC(hipMemsetAsync(y, 0xFF, (size_t)3 * S.n_loc * sizeof(double), stream));
   return PGO_OK;
 }
@@ -1572,11 +1602,33 @@ int pgo_handle::lm_iteration(bool* stop) {
     } else {
       dl_dear_run = dear ? dl_dear_run + 1 : 0;
       if (dl_dear_run >= 2) {
-        if (!dl_ready) PGOC(direct_setup(S.n_poses, true));
-        direct = true;
-        dl_last_probe = iter;
-        if (dl_switched_at == 0) dl_switched_at = iter;
-        if (opt.verbose) printf("pgo: %d PCG iterations in LM iteration %d: the direct solve takes over (rank %d)\n", k_it, iter, dl_K);
+        // The direct solver's buffers (~1 GB at rank 5862, more with long chains) are allocated HERE, in the middle of a
+        // solve that PCG is handling: a failed allocation must not turn a speed-up heuristic into a failed pgo_solve.
+        // Any failure -> the partial buffers are freed, the handle stays on PCG for good, the error text is cleared.
+        bool ok = true;
+        if (!dl_ready) {
+          const size_t mark = allocs.size();
+          const int64_t bytes_mark = device_bytes;
+          if (direct_setup(S.n_poses, true) != PGO_OK || !dl_ready) {
+            (void)hipStreamSynchronize(stream);   // uploads into the buffers about to be freed
+            (void)hipGetLastError();
+            for (size_t k = mark; k < allocs.size(); ++k) (void)hipFree(allocs[k]);
+            allocs.resize(mark);
+            device_bytes = bytes_mark;
+            clear_direct_buffers();
+            dl_possible = false;
+            direct = false;
+            ok = false;
+            (void)fail(PGO_OK, "");
+            if (opt.verbose) printf("pgo: the direct solver could not be set up (LM iteration %d): staying on PCG\n", iter);
+          }
+        }
+        if (ok) {
+          direct = true;
+          dl_last_probe = iter;
+          if (dl_switched_at == 0) dl_switched_at = iter;
+          if (opt.verbose) printf("pgo: %d PCG iterations in LM iteration %d: the direct solve takes over (rank %d)\n", k_it, iter, dl_K);
+        }
       }
     }
   }
@@ -1633,12 +1685,24 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
   R.pcg_rel_residual = rel;
   // model_cost_change = -(J d).(r + J d / 2), d = -S y   ==   y.gs - y.(H y) / 2
   if (!solo) {  // (the one-workgroup solve has done all of this in its epilogue; the gather vector holds y either way)
-    if (has_sw) {  // the switch back-substitution below reads y of both endpoints from the gather vector
+    // The model decrease below uses r = b - (H + D'D) y.  PCG's recurrence residual is that up to rounding drift, which
+    // grows with the iteration count: in the exact mode (tight tolerance, up to 1e5 iterations on the ill-conditioned
+    // late systems) the drift would bias rho and with it the accept / reject and radius decisions, unnoticed -- so
+    // there the residual is recomputed with one product (nothing next to the solve it follows).  The inexact mode
+    // (rtol 0.1, ~100 iterations) keeps the recurrence residual; the direct solve writes the true residual itself.
+    const bool true_residual = k_it > 0 && (opt.pcg_rtol < 1e-6 || k_it > 1000);
+    if (has_sw || true_residual) {  // (the switch back-substitution below reads y of both endpoints from the gather vector)
       hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
       PGOC(check_launch("k_scatter_owned"));
       PGOC(share_gather_vector(p_full));
     }
-    // y.(H y) = y.b - y.r - y.(D y) from the PCG residual (no product by H): part[1] = y.b, part[0] = y.r, part[5] = y.(D y)
+    if (true_residual) {
+      PGOC(spmv_enqueue(p_full, ap, part[0], 1, nullptr));
+      hipLaunchKernelGGL(dev::k_dlr_resid, dim3((3 * S.n_loc + 255) / 256), dim3(256), 0, stream, (int64_t)3 * S.n_loc, (const double*)gs,
+                         (const double*)ap, r);
+      PGOC(check_launch("k_dlr_resid"));
+    }
+    // y.(H y) = y.b - y.r - y.(D y) from the residual (no further product by H): part[1] = y.b, part[0] = y.r, part[5] = y.(D y)
     hipLaunchKernelGGL(dev::k_model_terms, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs,
                        (const double*)r, (const double*)d2, part[1], part[0], part[5]);
     PGOC(check_launch("k_model_terms"));
@@ -1866,7 +1930,9 @@ void pgo_options_default(pgo_options* o) {
   o->sc_prior_lambda = 1.0;
   o->pose_ordering = -1;
   o->pcg_chain_len = -1;
-  o->halo_exchange = 1;  // point-to-point exchange of the referenced rows; 0 = all-gather
+  o->halo_exchange = 0;  // all-gather (has run through RCCL, capturable); 1 = point-to-point exchange of the referenced rows:
+                         // opt-in like halo_overlap until a multi-GPU run has checked it against the all-gather (bench.py does
+                         // that check itself when it runs on several GPUs and then times the verified p2p path)
   o->halo_overlap = 0;   // opt-in: the two-stream schedule has never run against a real peer (no multi-GPU lease yet)
   o->linear_solver = 0;  // auto: the direct chain + low-rank solve on small chain-like graphs in the exact mode, else PCG
 }
@@ -2133,6 +2199,16 @@ int pgo_debug_phase_times(pgo_t* h, unsigned long long* out16) {
   return PGO_OK;
 }
 #endif
+
+int pgo_debug_set_knob(const char* name, long long value) {
+  if (!name) return fail(PGO_ERR_INVALID_ARG, "pgo_debug_set_knob: null name");
+  for (Knob& k : g_knobs)
+    if (!strcmp(k.name, name)) {
+      k.value.store(value < 0 ? -1 : value);
+      return PGO_OK;
+    }
+  return fail(PGO_ERR_INVALID_ARG, std::string("pgo_debug_set_knob: unknown knob ") + name);
+}
 
 int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   if (!h || !out) return fail(PGO_ERR_INVALID_ARG, "pgo_get_info: null");
@@ -2649,6 +2725,7 @@ int pgo_debug_precond(pgo_t* h, const double* r_in, double* z_out) {
     src = tmp.data();
   }
   HIPC(hipMemcpyAsync(h->ap, src, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));  // ap: scratch input
+  if (h->direct) PGOC(h->prepare_preconditioner());   // (a handle on the direct solve does not factorise it per LM iteration)
   dev::CgVec V = h->cg_vec();
   if (h->chain_len) {
     h->launch_cg_init_chain(h->ap, h->part[0], h->part[1]);
@@ -2721,9 +2798,31 @@ int pgo_bench_spmv(pgo_t* h, int reps, pgo_kernel_stats* out) {
   if (!h->lin_valid) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_spmv: call pgo_lm_begin first");
   HIPC(hipSetDevice(h->device));
   double ms = 0;
-  const char* ab = getenv("PGO_SPMV_ABLATE");
+  const char* ab = PGO_EXP_ENV("PGO_SPMV_ABLATE");
   h->spmv_ablate = ab ? atoi(ab) : 0;
-  int st_ab = time_launches(h, reps, [&] { (void)h->spmv_enqueue(h->p_full, h->ap, h->part[0], 1, nullptr); }, &ms);
+  int st_ab = PGO_OK;
+#ifdef PGO_EXPERIMENTS
+  // PGO_SPMV_PSTRIDE = 12 | 36: the product kernel on a copy of p spread over 96 / 288 bytes per pose (timing only; the
+  // result is the same product) -- are the gathers served by the Infinity Cache or by HBM?
+  const char* pstr = getenv("PGO_SPMV_PSTRIDE");
+  const int stride = pstr ? atoi(pstr) : 0;
+  if ((stride == 12 || stride == 36) && h->spmv_pipe) {
+    double* big = nullptr;
+    const int64_t nf = h->n_full;
+    HIPC(hipMalloc((void**)&big, (size_t)nf * stride * sizeof(double)));
+    HIPC(hipMemsetAsync(big, 0, (size_t)nf * stride * sizeof(double), h->stream));
+    HIPC(hipMemcpy2DAsync(big, (size_t)stride * sizeof(double), h->p_full, 3 * sizeof(double), 3 * sizeof(double), (size_t)nf,
+                          hipMemcpyDeviceToDevice, h->stream));
+    dev::SpmvArgs A = h->spmv_args(big, h->ap, h->part[0], 1, nullptr);
+    st_ab = time_launches(h, reps, [&] {
+      if (stride == 12) hipLaunchKernelGGL(dev::k_spmv_p<12>, dim3(h->g_spmv), dim3(dev::WG), 0, h->stream, A);
+      else hipLaunchKernelGGL(dev::k_spmv_p<36>, dim3(h->g_spmv), dim3(dev::WG), 0, h->stream, A);
+    }, &ms);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(big);
+  } else
+#endif
+  st_ab = time_launches(h, reps, [&] { (void)h->spmv_enqueue(h->p_full, h->ap, h->part[0], 1, nullptr); }, &ms);
   h->spmv_ablate = 0;
   PGOC(st_ab);
   out->ms_avg = ms;
@@ -2739,6 +2838,7 @@ int pgo_bench_precond(pgo_t* h, int reps, pgo_kernel_stats* out) {
   if (!h || !out || reps < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_precond: bad argument");
   if (!h->lin_valid || h->iter < 1) return fail(PGO_ERR_INVALID_ARG, "pgo_bench_precond: run at least one LM iteration first");
   HIPC(hipSetDevice(h->device));
+  if (h->direct) PGOC(h->prepare_preconditioner());   // (a handle on the direct solve does not factorise it per LM iteration)
   dev::CgVec V = h->cg_vec();
   double ms = 0;
   const double nl = (double)h->S.n_loc;
