@@ -162,7 +162,8 @@ typedef struct pgo_options {
   int32_t pose_ordering;       /* internal numbering of the poses (results are always in the caller's numbering):
                                   0 = the caller's, 1 = locality ordering (pgo_pose_order: segments of 64 consecutive
                                   poses reordered by reverse Cuthill-McKee on the loop edges that a neighbouring edge
-                                  supports), -1 (default) = 1 when world > 1 (it shrinks every rank's halo), else 0  */
+                                  supports), -1 (default) = 1 when world > 1 (it shrinks every rank's halo) and on single-rank
+                                  graphs of more than 65536 poses (the gathers of K1 / K2 / K3 then hit the XCD's L2), else 0 */
   int32_t info_weighting;      /* 0 (default) = the reference's objective: the information entries of an edge are parsed
                                   but unused.  1 = optional mode: every residual is whitened by
                                   its information matrix, e_w = L' e with Omega = L L', so |e_w|^2 = e' Omega e (the chi2

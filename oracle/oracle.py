@@ -28,6 +28,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_VARIANTS = {}
+
+# compiler flags of the CPU-baseline variants bench.py times next to the default build (oracle/Makefile: -O2 -fopenmp)
+VARIANT_FLAGS = {"O3-native": "-O3 -march=native -fopenmp -fPIC -std=c11 -D_POSIX_C_SOURCE=200809L",
+                 "O0": "-O0 -fopenmp -fPIC -std=c11 -D_POSIX_C_SOURCE=200809L"}
 
 
 def build(force: bool = False) -> str:
@@ -35,6 +40,23 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "pgo_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpgo_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def build_variant(name: str) -> str:
+    """the same source with other compiler flags (VARIANT_FLAGS), built where it runs (-march=native): libpgo_oracle_<name>.so"""
+    tag = name
+    if "native" in VARIANT_FLAGS[name]:   # machine-specific code: never reuse a build from another CPU (the tree travels to the GPU box)
+        import hashlib
+        try:
+            model = [l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags"))][:2]
+        except OSError:
+            model = []
+        tag += "_" + hashlib.sha256("".join(model).encode()).hexdigest()[:10]
+    so = os.path.join(_HERE, "libpgo_oracle_%s.so" % tag)
+    src = os.path.join(_HERE, "pgo_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc"] + VARIANT_FLAGS[name].split() + ["-shared", "-o", so, src, "-lm"])
     return so
 
 
@@ -60,33 +82,41 @@ class _Summary(C.Structure):
                                           "seconds_assemble", "seconds_linear", "seconds_candidate")]
 
 
-def lib():
+def lib(variant=None):
+    """the oracle library; variant = a key of VARIANT_FLAGS selects the same source built with those flags"""
     global _LIB
+    if variant is not None:
+        if variant not in _VARIANTS:
+            _VARIANTS[variant] = _bind(C.CDLL(build_variant(variant)))
+        return _VARIANTS[variant]
     if _LIB is None:
-        L = C.CDLL(build())
-        dp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
-        L.pgo_oracle_edge.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp]
-        L.pgo_oracle_edge.restype = None
-        L.pgo_oracle_huber.argtypes = [C.c_double, C.c_double, dp]
-        L.pgo_oracle_huber.restype = None
-        L.pgo_oracle_edge_w.argtypes = [dp, dp, dp, dp, C.c_int, C.c_double, dp, dp]
-        L.pgo_oracle_edge_w.restype = None
-        L.pgo_oracle_edge_chi2.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, dp]
-        L.pgo_oracle_edge_chi2.restype = None
-        L.pgo_oracle_eval_w.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, bp, C.c_int, C.c_double, C.c_double,
-                                        C.c_int, dp, dp, C.c_int]
-        L.pgo_oracle_eval_w.restype = C.c_double
-        L.pgo_oracle_eval_sc.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, dp, C.c_double, C.c_double, C.c_int, dp, dp,
-                                         dp, dp, C.c_int]
-        L.pgo_oracle_eval_sc.restype = C.c_double
-        L.pgo_oracle_lm_pcg_w.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, bp, C.POINTER(_Opts), C.POINTER(_Iter),
-                                          C.c_int, C.POINTER(C.c_int), C.POINTER(_Summary)]
-        L.pgo_oracle_lm_pcg_w.restype = C.c_int
-        L.pgo_oracle_normal_eq_w.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, bp, C.c_int, C.c_double, C.c_double,
-                                             C.c_int, dp, dp, dp, dp, dp, C.c_int]
-        L.pgo_oracle_normal_eq_w.restype = C.c_int
-        _LIB = L
+        _LIB = _bind(C.CDLL(build()))
     return _LIB
+
+
+def _bind(L):
+    dp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    L.pgo_oracle_edge.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp]
+    L.pgo_oracle_edge.restype = None
+    L.pgo_oracle_huber.argtypes = [C.c_double, C.c_double, dp]
+    L.pgo_oracle_huber.restype = None
+    L.pgo_oracle_edge_w.argtypes = [dp, dp, dp, dp, C.c_int, C.c_double, dp, dp]
+    L.pgo_oracle_edge_w.restype = None
+    L.pgo_oracle_edge_chi2.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, dp]
+    L.pgo_oracle_edge_chi2.restype = None
+    L.pgo_oracle_eval_w.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, bp, C.c_int, C.c_double, C.c_double,
+                                    C.c_int, dp, dp, C.c_int]
+    L.pgo_oracle_eval_w.restype = C.c_double
+    L.pgo_oracle_eval_sc.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, bp, dp, C.c_double, C.c_double, C.c_int, dp, dp,
+                                     dp, dp, C.c_int]
+    L.pgo_oracle_eval_sc.restype = C.c_double
+    L.pgo_oracle_lm_pcg_w.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, bp, C.POINTER(_Opts), C.POINTER(_Iter),
+                                      C.c_int, C.POINTER(C.c_int), C.POINTER(_Summary)]
+    L.pgo_oracle_lm_pcg_w.restype = C.c_int
+    L.pgo_oracle_normal_eq_w.argtypes = [C.c_int, dp, C.c_int, ip, ip, dp, dp, bp, C.c_int, C.c_double, C.c_double,
+                                         C.c_int, dp, dp, dp, dp, dp, C.c_int]
+    L.pgo_oracle_normal_eq_w.restype = C.c_int
+    return L
 
 
 def _dp(a):
@@ -491,8 +521,9 @@ def lm_direct(g: Graph, opt: Options = Options()) -> Result:
     return res
 
 
-def lm_pcg(g: Graph, opt: Options = Options()) -> Result:
-    """Same LM policy, linear solve by block-Jacobi PCG, all in C (OpenMP): the CPU "port"."""
+def lm_pcg(g: Graph, opt: Options = Options(), variant=None) -> Result:
+    """Same LM policy, linear solve by block-Jacobi PCG, all in C (OpenMP): the CPU "port".
+    variant: a key of VARIANT_FLAGS = the same source built with other compiler flags (bench.py's CPU-baseline sweep)."""
     o = _Opts(opt.method, opt.max_iters, opt.fixed_pose, opt.jacobi_scaling, opt.phi, opt.huber_delta, opt.ftol,
               opt.gtol, opt.ptol, opt.radius0, opt.max_radius, opt.min_radius, opt.min_relative_decrease,
               opt.min_lm_diagonal, opt.max_lm_diagonal, opt.pcg_rtol, opt.pcg_max_iters, opt.threads, opt.verbose,
@@ -505,7 +536,7 @@ def lm_pcg(g: Graph, opt: Options = Options()) -> Result:
     ia, ib = np.ascontiguousarray(g.ia, np.int32), np.ascontiguousarray(g.ib, np.int32)
     meas, kind = np.ascontiguousarray(g.meas, np.float64), np.ascontiguousarray(g.kind, np.uint8)
     w = _info(g, opt.info_weighting)
-    lib().pgo_oracle_lm_pcg_w(g.n_poses, _dp(x), g.n_edges, _ip(ia), _ip(ib), _dp(meas), _dp(w), _bp(kind), C.byref(o), recs,
+    lib(variant).pgo_oracle_lm_pcg_w(g.n_poses, _dp(x), g.n_edges, _ip(ia), _ip(ib), _dp(meas), _dp(w), _bp(kind), C.byref(o), recs,
                               cap, C.byref(nrec), C.byref(summ))
     out = Result(x, summ.termination, summ.iterations, summ.successful_steps, summ.initial_cost, summ.final_cost)
     out.total_pcg_iters = summ.total_pcg_iters

@@ -655,6 +655,8 @@ struct SpmvArgs {
   const double* hoff;        // AoSoA, see hoff_index
   const double* hd;          // 6 planes
   const double* d2;          // [n_loc x 3] LM diagonal D'D
+  const double* hdd;         // 3 planes [n_loc]: diagonal of (J_self)'(J_self) + D'D (k_prepare); read by k_spmv_p instead of
+                             // the three diagonal planes of hd AND d2 -- 24 B per row less
   const double* p;           // gathered vector, GLOBAL indexing [.. x 3]
   double* y;                 // [n_loc x 3]
   double* dot_part;          // [gridDim.x] partial of p_owned . y
@@ -880,7 +882,7 @@ __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
   const XcdRange xr = xcd_range(A.n_tiles);
   struct Lane {
     double h[9], p0, p1, p2;     // lane phase: block + gathered direction
-    double h0, h1, h2, dd, pr0, pr1, pr2;   // row phase: diagonal row, LM diagonal, own direction
+    double h0, h1, h2, pr0, pr1, pr2;       // row phase: row a of the diagonal block (LM diagonal folded in), own direction
     int a, row, lo, hi;
     bool on, pv;
   };
@@ -889,18 +891,24 @@ __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
     const int r0 = d.x, nrows = d.y, q0 = d.z, nq = d.w;
     L.pv = tid < nrows * 3;
     L.a = 0; L.row = r0; L.lo = 0; L.hi = 0;
-    L.h0 = L.h1 = L.h2 = L.dd = L.pr0 = L.pr1 = L.pr2 = 0.0;
+    L.h0 = L.h1 = L.h2 = L.pr0 = L.pr1 = L.pr2 = 0.0;
     if (L.pv) {
       L.a = tid / nrows;
       L.row = r0 + (tid - L.a * nrows);
       L.lo = A.inc_ptr[L.row] - q0;
       L.hi = A.inc_ptr[L.row + 1] - q0;
       const int a = L.a;
-      const int i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
-      L.h0 = ld_stream(A.hd + ((int64_t)a * n + L.row));
-      L.h1 = ld_stream(A.hd + ((int64_t)i1 * n + L.row));
-      L.h2 = ld_stream(A.hd + ((int64_t)i2 * n + L.row));
-      if (A.with_d2) L.dd = ld_stream(A.d2 + (3 * (int64_t)L.row + a));
+      // symmetric row a of the diagonal block: (h0, h1, h2) multiply (p0, p1, p2); the diagonal entry comes with D'D
+      // already added (hdd) when the product includes the LM diagonal
+      const int i0 = (a == 0) ? 0 : a, i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
+      const double* hdg = A.with_d2 ? A.hdd + ((int64_t)a * n + L.row) : A.hd + ((int64_t)(a == 0 ? 0 : (a == 1 ? 3 : 5)) * n + L.row);
+      const double dg = ld_stream(hdg);
+      const double o0 = (a == 0) ? 0.0 : ld_stream(A.hd + ((int64_t)i0 * n + L.row));
+      const double o1 = (a == 1) ? 0.0 : ld_stream(A.hd + ((int64_t)i1 * n + L.row));
+      const double o2 = (a == 2) ? 0.0 : ld_stream(A.hd + ((int64_t)i2 * n + L.row));
+      L.h0 = (a == 0) ? dg : o0;
+      L.h1 = (a == 1) ? dg : o1;
+      L.h2 = (a == 2) ? dg : o2;
       gather3<PSTR>(A.p, (int64_t)A.lo + L.row, L.pr0, L.pr1, L.pr2);
     }
     L.on = tid < nq;
@@ -941,7 +949,7 @@ __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
       // row operands of tile t stay; everything of tile t + 1 goes out now
       const bool pv = L.pv;
       const int a = L.a, row = L.row, lo = L.lo, hi = L.hi;
-      const double h0 = L.h0, h1 = L.h1, h2 = L.h2, dd = L.dd, pr0 = L.pr0, pr1 = L.pr1, pr2 = L.pr2;
+      const double h0 = L.h0, h1 = L.h1, h2 = L.h2, pr0 = L.pr0, pr1 = L.pr1, pr2 = L.pr2;
       if (tn < xr.end) L = issue(d1, col1);
       int col2 = 0;
       if (tnn < xr.end) col2 = (tid < d2.w) ? ld_stream(A.inc_col + d2.z + tid) : 0;
@@ -950,7 +958,7 @@ __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
         double s = 0.0;
         for (int j = lo; j < hi; ++j) s += scr[buf][a][j];
         const double pa = (a == 0) ? pr0 : (a == 1 ? pr1 : pr2);
-        s += h0 * pr0 + h1 * pr1 + h2 * pr2 + dd * pa;
+        s += h0 * pr0 + h1 * pr1 + h2 * pr2;
         st_stream(A.y + (3 * (int64_t)row + a), s);
         dot += pa * s;
       }
@@ -1039,7 +1047,7 @@ __global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo,
 __global__ void k_prepare(const double* __restrict__ hd, const double* __restrict__ diag_full, int n_loc, int lo, int fixed,
                           double radius, double dmin, double dmax, double* __restrict__ d2, double* __restrict__ minv,
                           const uint8_t* __restrict__ fixed_mask, const int32_t* __restrict__ prob_of_256,
-                          const double* __restrict__ prob_radius, double* __restrict__ chain_rec) {
+                          const double* __restrict__ prob_radius, double* __restrict__ chain_rec, double* __restrict__ hdd) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_loc) return;
   if (fixed_mask && fixed_mask[row]) fixed = lo + row;
@@ -1059,6 +1067,11 @@ __global__ void k_prepare(const double* __restrict__ hd, const double* __restric
   a00 += e0;
   a11 += e1;
   a22 += e2;
+  if (hdd) {   // diagonal of H + D'D for the product kernel (k_spmv_p)
+    hdd[row] = a00;
+    hdd[n + row] = a11;
+    hdd[2 * n + row] = a22;
+  }
   if (chain_rec) {  // chain preconditioner: M_ii = H_ii + D'D into the factorisation's input record (the 3x3 inverse below is unused)
     double2* o = reinterpret_cast<double2*>(chain_rec + (int64_t)row * CHAIN_REC);
     o[0] = make_double2(a00, a01);

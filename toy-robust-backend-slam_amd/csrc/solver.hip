@@ -80,6 +80,7 @@ struct PartRef {
 };
 constexpr int N_SCAL = 16;
 constexpr int N_PART = 6;
+constexpr int DIRECT_MAX_POSES = 65536;   // largest graph the direct (chain + low-rank) solve takes
 }  // namespace
 
 struct pgo_handle {
@@ -110,7 +111,7 @@ struct pgo_handle {
   bool spmv_pipe = false;   // software-pipelined K3 (k_spmv_p): when no tile is a chunked heavy row or has > 85 rows
   int64_t inc_stride = 0;
   // normal equations
-  double *hoff = nullptr, *hd = nullptr, *gs = nullptr, *d2 = nullptr, *minv = nullptr;
+  double *hoff = nullptr, *hd = nullptr, *gs = nullptr, *d2 = nullptr, *minv = nullptr, *hdd = nullptr;
   // CG
   double *y = nullptr, *r = nullptr, *z = nullptr, *ap = nullptr, *p_full = nullptr;
   dev::CgState* st = nullptr;
@@ -438,6 +439,7 @@ struct pgo_handle {
     A.hoff = hoff;
     A.hd = hd;
     A.d2 = d2;
+    A.hdd = hdd;
     A.p = p;
     A.y = yout;
     A.dot_part = dot_part;
@@ -610,7 +612,10 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     return fail(PGO_ERR_INVALID_ARG, "pcg_chain_len: a multiple of 4 that divides 256 (4 ... 256), 0 = off, -1 = auto");
   if (chain_len) grp_B = 1;
   // internal pose numbering
-  const bool reorder = opt.pose_ordering == 1 || (opt.pose_ordering < 0 && world > 1);
+  // auto: several ranks (it shrinks every rank's halo 2.6-2.9x), and single-rank graphs too large for the direct solve, where
+  // it is worth -11 % of K3's fabric traffic (977 -> 870 MB per product at 1M poses: the gathers of neighbouring tiles hit
+  // the XCD's L2), -16 % of K2's and -22 % of K1's reads: 38.7 / 40.1 -> 39.7 / 41.5 GN it/s (profiles/r03_order.md)
+  const bool reorder = opt.pose_ordering == 1 || (opt.pose_ordering < 0 && (world > 1 || N > DIRECT_MAX_POSES));
   std::vector<int32_t> ia_p, ib_p;
   std::vector<double> poses_p;
   fixed_internal = opt.fixed_pose;
@@ -660,6 +665,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(dalloc(&gs, 3 * NL));
   PGOC(dalloc(&d2, 3 * NL));
   PGOC(dalloc(&minv, 6 * NL));
+  PGOC(dalloc(&hdd, 3 * NL));
   PGOC(dalloc(&y, 3 * NL));
   PGOC(dalloc(&r, 3 * NL));
   PGOC(dalloc(&z, 3 * NL));
@@ -1034,7 +1040,6 @@ int pgo_handle::lm_begin() {
 // SPARSE_NORMAL_CHOLESKY, main.cpp:154-163) and only while the caller left the preconditioner to the library; it needs
 // one rank, METHOD 0 / 1, a constant pose, an edge between every pair of consecutive poses, and few enough other edges.
 namespace {
-constexpr int DIRECT_MAX_POSES = 65536;
 constexpr int DIRECT_MAX_RANK = 6144;   // 3 x (edges outside the chain) + 1: order of the dense capacitance matrix
 constexpr double PCG_SECONDS_PER_ITER_SMALL = 14e-6;   // a PCG iteration of the two-launch loop on graphs of a few thousand poses
 constexpr int DIRECT_PROBE_EVERY = 10;
@@ -1673,7 +1678,7 @@ int pgo_handle::factor_chain() {
 int pgo_handle::prepare_system() {
   hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, (const double*)diag_full, S.n_loc, S.lo, fixed_internal, radius,
                      opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv, (const uint8_t*)fixed_mask, (const int32_t*)prob_of_256,
-                     (const double*)prob_radius, chain_len ? chain_c : (double*)nullptr);
+                     (const double*)prob_radius, chain_len ? chain_c : (double*)nullptr, hdd);
   PGOC(check_launch("k_prepare"));
   if (!direct) PGOC(prepare_preconditioner());   // (the direct solve does not need it; its PCG fallback sets it up on demand)
   return PGO_OK;
@@ -2828,8 +2833,8 @@ int pgo_bench_spmv(pgo_t* h, int reps, pgo_kernel_stats* out) {
   out->ms_avg = ms;
   out->units = h->S.n_inc + h->S.n_loc;
   // 76 B per off-diagonal block (value + column) ; per row: 48 B diagonal planes + 24 B D'D + 4 B row
-  // pointer + 24 B y + 24 B p
-  out->algorithmic_bytes = 76.0 * (double)h->S.n_inc + 124.0 * h->S.n_loc;
+  // pointer + 24 B y + 24 B p; the product kernel k_spmv_p reads the diagonal with D'D folded in (k_prepare): 24 B less
+  out->algorithmic_bytes = 76.0 * (double)h->S.n_inc + (h->spmv_pipe ? 100.0 : 124.0) * h->S.n_loc;
   return PGO_OK;
 }
 
