@@ -350,7 +350,8 @@ typedef struct pgo_handle_info {
   int32_t direct_fallbacks;          /* LM iterations whose direct solve gave no usable step and were redone by PCG  */
   int32_t direct_switched_at;        /* auto, rank above 2048: the LM iteration after which the direct solve took over from PCG
                                         (its PCG solve cost more than a direct solve of this rank does), 0 = it has not       */
-  int32_t _pad;
+  int32_t pcg_single_reduction;      /* 1 = the PCG loop with ONE reduction point per iteration (Chronopoulos-Gear recurrences:
+                                        world > 1, pcg_rtol >= 1e-6, chain preconditioner), 0 = the textbook two-reduction loop */
 } pgo_handle_info;
 int pgo_get_info(const pgo_t* h, pgo_handle_info* out);                           /* [host] */
 

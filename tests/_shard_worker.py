@@ -22,10 +22,12 @@ def main():
         comm = P.Comm.rccl(P.Comm.unique_id(), rank, world, 0)
     else:
         comm = P.Comm.shm(cfg["name"], rank, world, 0) if world > 1 else None
+    for k, v in (cfg.get("knobs") or {}).items():   # test hooks (pgo_debug_set_knob), read when the handle is created
+        P.set_knob(k, v)
     s = P.Solver(g, P.Options(**cfg["options"]), comm, device=0)
     c0, _, _ = s.evaluate(want_r=False, want_J=False)
     summ = s.solve()
-    out = dict(cost0=c0, summary=summ.as_dict(), records=s.iter_records())
+    out = dict(cost0=c0, summary=summ.as_dict(), records=s.iter_records(), info=s.info().as_dict())
     np.save(os.path.join(cfg["out"], "poses_%d.npy" % rank), s.poses())
     if cfg.get("chi2"):
         np.save(os.path.join(cfg["out"], "chi2_%d.npy" % rank), s.edge_chi2())

@@ -142,3 +142,45 @@ def test_halo_overlap_matches_plain_exchange(tmp_path, world, chain):
                 assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 1
         assert np.abs(poses[0] - ref_poses[0]).max() < 1e-6
     assert np.abs(out[0][1][0] - out[1][1][0]).max() < 1e-9
+
+
+@pytest.mark.parametrize("world,halo,rtol", [(2, 0, 0.1), (4, 1, 0.1), (3, 1, 1e-3), (2, 0, 1e-6)])
+def test_single_reduction_pcg_matches_two_reduction_loop(tmp_path, world, halo, rtol):
+    """several ranks, inexact mode (pcg_rtol >= 1e-6), chain preconditioner: the PCG loop with ONE reduction point per
+    iteration (k_cg_sr_*: Chronopoulos-Gear recurrences, (gamma, rr, delta) in one all-reduce) is the default; the same
+    solve with the textbook two-reduction loop (test hook) and on one rank gives the same LM history, PCG iteration counts
+    within 2 per LM iteration, and the same poses"""
+    base = dict(graph="synth", n_poses=30001, seed=11,
+                options=dict(method=1, max_iters=5, pcg_rtol=rtol, pcg_max_iters=20000, pcg_chain_len=64, halo_exchange=halo))
+    ref, ref_poses = run(1, base, tmp_path, tag="ref")
+    two, two_poses = run(world, dict(base, knobs=dict(single_reduction=0)), tmp_path, tag="two")
+    one, one_poses = run(world, base, tmp_path, tag="one")
+    assert ref[0]["info"]["pcg_single_reduction"] == 0 and two[0]["info"]["pcg_single_reduction"] == 0
+    for r in range(world):
+        assert one[r]["info"]["pcg_single_reduction"] == 1
+        np.testing.assert_array_equal(one_poses[r], one_poses[0])
+        for a, b, c in zip(one[r]["records"], two[r]["records"], ref[0]["records"]):
+            assert a["step_ok"] == b["step_ok"] == c["step_ok"]
+            assert a["cost"] == pytest.approx(b["cost"], rel=1e-8) and a["cost"] == pytest.approx(c["cost"], rel=1e-8)
+            assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 2 and abs(a["pcg_iters"] - c["pcg_iters"]) <= 2
+            assert a["iter"] == 0 or a["pcg_rel_residual"] <= rtol
+    print("world %d rtol %g: PCG iterations one-reduction %d, two-reduction %d, one rank %d; host enqueue %.1f / %.1f us per PCG iteration"
+          % (world, rtol, one[0]["summary"]["total_pcg_iters"], two[0]["summary"]["total_pcg_iters"], ref[0]["summary"]["total_pcg_iters"],
+             one[0]["info"]["host_enqueue_us_per_pcg_iter"], two[0]["info"]["host_enqueue_us_per_pcg_iter"]))
+    assert np.abs(one_poses[0] - two_poses[0]).max() < 1e-6 and np.abs(one_poses[0] - ref_poses[0]).max() < 1e-6
+
+
+def test_single_reduction_pcg_in_a_captured_graph_with_rccl(tmp_path):
+    """world == 1 through RCCL with the collectives forced on: the one-reduction loop -- kernels, all-gather, all-reduce --
+    is captured into the PCG hipGraph and replayed; same result as the plain single-rank solve.  The exact mode
+    (pcg_rtol < 1e-6) keeps the two-reduction loop."""
+    base = dict(graph="synth", n_poses=60001, seed=4, options=dict(method=1, max_iters=4, pcg_rtol=0.1, pcg_max_iters=500))
+    ref, ref_poses = run(1, base, tmp_path, tag="ref")
+    res, poses = run(1, dict(base, comm="rccl"), tmp_path, env={"PGO_FORCE_COLLECTIVES": "1"}, tag="rccl")
+    assert res[0]["info"]["pcg_single_reduction"] == 1 and res[0]["info"]["pcg_graph_replay"] == 1
+    for a, b in zip(res[0]["records"], ref[0]["records"]):
+        assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-8) and abs(a["pcg_iters"] - b["pcg_iters"]) <= 2
+    assert np.abs(poses[0] - ref_poses[0]).max() < 1e-6
+    tight, _ = run(1, dict(base, comm="rccl", options=dict(base["options"], pcg_rtol=1e-9, pcg_max_iters=50000, max_iters=2)), tmp_path,
+                   env={"PGO_FORCE_COLLECTIVES": "1"}, tag="tight")
+    assert tight[0]["info"]["pcg_single_reduction"] == 0

@@ -104,7 +104,7 @@ class HandleInfo(C.Structure):
                 ("chain_kernel", C.c_int32), ("pose_ordering", C.c_int32), ("halo_exchange", C.c_int32),
                 ("halo_overlap", C.c_int32), ("halo_send_rows", C.c_int64), ("halo_recv_rows", C.c_int64),
                 ("device_bytes", C.c_int64), ("host_enqueue_us_per_pcg_iter", C.c_double), ("pcg_graph_replay", C.c_int32),
-                ("linear_solver", C.c_int32), ("direct_rank", C.c_int32), ("direct_fallbacks", C.c_int32), ("direct_switched_at", C.c_int32), ("_pad", C.c_int32)]
+                ("linear_solver", C.c_int32), ("direct_rank", C.c_int32), ("direct_fallbacks", C.c_int32), ("direct_switched_at", C.c_int32), ("pcg_single_reduction", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

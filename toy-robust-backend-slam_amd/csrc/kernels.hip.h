@@ -639,6 +639,8 @@ struct CgState {       // lives in device memory
   int32_t pending;     // fused-update loop (k_spmv MODE 5): an iteration's r.z / r.r partials wait to be booked
   int32_t started;     // fused-update loop: 0 until the first k_cg_update1 of the solve has run.  Written by k_cg_init_fin and
                        // k_cg_update1* only -- never during a k_spmv launch, whose workgroups all read it
+  // single-reduction loop (k_cg_sr_*): coefficients of the coming vector update, written by k_cg_sr_scal only
+  double sr_alpha, sr_beta, sr_gamma;
 };
 
 struct SpmvArgs {
@@ -2316,6 +2318,132 @@ __global__ __launch_bounds__(64 * NW) void k_cg_update1_cl(CgVec V, ChainPre C, 
     V.st->started = 1;
   }
   PGO_T(6);
+}
+
+// ------------------------------------------------- single-reduction PCG (Chronopoulos & Gear), chain preconditioner
+// Several ranks: the textbook loop has two dependent reduction points per iteration (p.Ap, then r.z / r.r), i.e. two
+// latency-bound all-reduces.  This form carries s = A p by recurrence, so that ONE reduction per iteration suffices:
+//     u = M^-1 r,  w = A u,  gamma = r.u,  delta = w.u,  rr = r.r            (all three reduced together)
+//     beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old)
+//     p = u + beta p,  s = w + beta s,  x += alpha p,  r -= alpha s
+// The iterates equal the textbook ones in exact arithmetic; the recurrence for s drifts from A p over thousands of
+// iterations on the ill-conditioned systems of the exact mode (measured in round 2: MIT at radius 3e11 stagnates above
+// 1e-10), so the host takes this loop only for pcg_rtol >= 1e-6.
+// Kernels per iteration: k_cg_sr_cl (everything above on the vectors + the chain apply + partials of gamma, rr), the
+// exchange of u, the product w = A u with its delta partial (K3), k_finalize + ONE all-reduce of (gamma, rr, delta),
+// k_cg_sr_scal.  u lives in the gather vector (V.p, global indexing), p in V.z, s in `sv`, w in V.ap.
+
+// scal = (gamma, rr, delta) reduced over workgroups and ranks; first != 0: start of a solve (scal[1] = b.b)
+__global__ void k_cg_sr_scal(CgState* st, const double* __restrict__ scal, double rtol, int first) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double gamma = scal[0], rr = scal[1], delta = scal[2];
+  if (first) {
+    st->bb = rr;
+    st->tol2 = rtol * rtol * rr;
+    st->iters = 0;
+    st->pending = 0;
+    st->started = 0;
+    st->done = (rr == 0.0) ? 1 : 0;
+    st->rr = rr;
+    st->sr_beta = 0.0;
+    st->sr_alpha = gamma / delta;
+    st->sr_gamma = gamma;
+    st->rz[0] = st->rz[1] = gamma;
+    return;
+  }
+  if (st->done) return;
+  st->iters += 1;          // the vector update that produced this residual
+  st->rr = rr;
+  if (rr <= st->tol2) {
+    st->done = 1;
+    return;
+  }
+  const double beta = gamma / st->sr_gamma;
+  st->sr_alpha = gamma / (delta - beta * gamma / st->sr_alpha);
+  st->sr_beta = beta;
+  st->sr_gamma = gamma;
+}
+
+template <int CH, int NW>
+__global__ __launch_bounds__(64 * NW) void k_cg_sr_cl(CgVec V, ChainPre C, double* __restrict__ sv, int n_steps, int scan_levels,
+                                                 double* __restrict__ part_gamma, double* __restrict__ part_rr) {
+  constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
+  __shared__ double tile[NW][64 * STRIDE];
+  __shared__ double red[8];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (V.st->done) return;       // (only k_cg_sr_scal writes the state, never during this launch)
+  const double alpha = V.st->sr_alpha, beta = V.st->sr_beta;
+  double* buf = tile[wave];
+  double* ch = buf + lane * STRIDE;
+  const int64_t n3 = 3 * (int64_t)V.n_loc, np = C.n_pad;
+  double* __restrict__ vx = V.y;
+  double* __restrict__ vr = V.r;
+  double* __restrict__ vp = V.z;
+  const double* __restrict__ vw = V.ap;
+  double* __restrict__ vu = V.p + 3 * (int64_t)V.lo;
+  double gam = 0.0, rr = 0.0;
+  const int64_t n_tiles = ((int64_t)V.n_loc + TILE - 1) / TILE;
+  for (int64_t t = (int64_t)blockIdx.x * NW + wave; t < n_tiles; t += (int64_t)gridDim.x * NW) {
+    const int64_t wbase = t * TILE, f0 = 3 * wbase;
+    const unsigned lim = (unsigned)(n3 - f0 < 3 * TILE ? n3 - f0 : 3 * TILE);
+    const double* cw_tile = C.cw + wbase;
+    double W[CH][9];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+      for (int c = 0; c < 9; ++c) W[k][c] = ld_stream(cw_tile + ((int64_t)c * np + k * 64) + lane);
+    double rv[NV];
+    {
+      double uv[NV], wv[NV], pv[NV], sq[NV], xv[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {   // clamped addresses: no load behind a branch (the partial last tile)
+        const unsigned e = lane + 64u * j, ec = e < lim ? e : 0u;
+        uv[j] = vu[f0 + ec];
+        wv[j] = ld_stream(vw + f0 + ec);
+        pv[j] = ld_stream(vp + f0 + ec);
+        sq[j] = ld_stream(sv + f0 + ec);
+        xv[j] = ld_stream(vx + f0 + ec);
+        rv[j] = ld_stream(vr + f0 + ec);
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const unsigned e = lane + 64u * j;
+        const bool ok = e < lim;
+        const double pn = uv[j] + beta * pv[j], sn = wv[j] + beta * sq[j];
+        const double xn = xv[j] + alpha * pn;
+        rv[j] = ok ? rv[j] - alpha * sn : 0.0;
+        if (ok) {
+          st_stream(vp + f0 + e, pn);
+          st_stream(sv + f0 + e, sn);
+          st_stream(vx + f0 + e, xn);
+          st_stream(vr + f0 + e, rv[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const unsigned e = lane + 64u * j;
+      rr += rv[j] * rv[j];
+      buf[e + e / (3 * CH)] = rv[j];
+    }
+    wave_lds_sync();
+    chain_apply_lean<CH>(W, C.cs + wbase, np, lane, ch, n_steps, scan_levels);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const unsigned e = lane + 64u * j;
+      const double u = buf[e + e / (3 * CH)];
+      if (e < lim) vu[f0 + e] = u;      // plain store: the next kernel gathers it
+      gam += rv[j] * u;
+    }
+    wave_lds_sync();
+  }
+  gam = block_sum_nw<NW>(gam, red);
+  rr = block_sum_nw<NW>(rr, red);
+  if (tid == 0) {
+    part_gamma[blockIdx.x] = gam;
+    part_rr[blockIdx.x] = rr;
+  }
 }
 
 // ------------------------------------------------- METHOD 2: switch variables, eliminated edge by edge

@@ -87,6 +87,9 @@ void compute_tile_order(const ShardStructure& S, std::vector<int32_t>* order);
 int compute_pose_order(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int32_t segment,
                        std::vector<int32_t>* perm);
 constexpr int ORDER_SEGMENT = 64;
+// the same through a small process-wide cache keyed by a hash of the edge list (repeated handles on one graph)
+int cached_pose_order(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int32_t segment,
+                      std::vector<int32_t>* perm);
 
 // poses per block of the block-Jacobi preconditioner for an option value (0 = auto)
 inline int resolve_block_poses(int opt_value, int32_t n_poses) {

@@ -114,6 +114,9 @@ struct pgo_handle {
   double *hoff = nullptr, *hd = nullptr, *gs = nullptr, *d2 = nullptr, *minv = nullptr, *hdd = nullptr;
   // CG
   double *y = nullptr, *r = nullptr, *z = nullptr, *ap = nullptr, *p_full = nullptr;
+  // single-reduction PCG loop (k_cg_sr_*: one all-reduce per iteration; several ranks, inexact mode, chain preconditioner)
+  bool use_sr = false;
+  double* sr_s = nullptr;   // s = A p, carried by recurrence
   dev::CgState* st = nullptr;
   dev::CgState* h_st = nullptr;  // pinned
   // reductions
@@ -552,6 +555,13 @@ struct pgo_handle {
     else if (chain_chunk == 4) hipLaunchKernelGGL((dev::k_cg_init_cl<4, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, chain_steps, chain_scan, b, part_rz, part_bb);
     else hipLaunchKernelGGL(dev::k_cg_init_c, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, b, part_rz, part_bb);
   }
+  void launch_cg_sr_chain(const dev::CgVec& V, double* part_gamma, double* part_rr) {
+    const dev::ChainPre CP = chain_pre();
+    if (chain_chunk == 2 && chain_nw == 4) hipLaunchKernelGGL((dev::k_cg_sr_cl<2, 4>), dim3(g_chain), dim3(256), 0, stream, V, CP, sr_s, chain_steps, chain_scan, part_gamma, part_rr);
+    else if (chain_chunk == 2) hipLaunchKernelGGL((dev::k_cg_sr_cl<2, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, sr_s, chain_steps, chain_scan, part_gamma, part_rr);
+    else if (chain_nw == 4) hipLaunchKernelGGL((dev::k_cg_sr_cl<4, 4>), dim3(g_chain), dim3(256), 0, stream, V, CP, sr_s, chain_steps, chain_scan, part_gamma, part_rr);
+    else hipLaunchKernelGGL((dev::k_cg_sr_cl<4, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, sr_s, chain_steps, chain_scan, part_gamma, part_rr);
+  }
   void launch_cg_update1_chain(const dev::CgVec& V, int par, const double* pap, int n_pap, double* part_rz, double* part_rr) {
     const dev::ChainPre CP = chain_pre();
     if (chain_chunk == 2 && chain_nw == 4) hipLaunchKernelGGL((dev::k_cg_update1_cl<2, 4>), dim3(g_chain), dim3(256), 0, stream, V, CP, chain_steps, chain_scan, par, pap, n_pap, part_rz, part_rr);
@@ -619,9 +629,35 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   std::vector<int32_t> ia_p, ib_p;
   std::vector<double> poses_p;
   fixed_internal = opt.fixed_pose;
+  HIPC(hipSetDevice(device));
+  HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   if (reorder) {
-    // chain segments must stay contiguous under the renumbering
-    PGOC(pgo::compute_pose_order(N, E, ia, ib, std::max<int>(pgo::ORDER_SEGMENT, chain_len), &perm));
+    // chain segments must stay contiguous under the renumbering.  The ordering is host work on the WHOLE edge list
+    // (0.7 s at 1M poses): a process-wide cache serves repeated handles on the same graph, and with several ranks only
+    // rank 0 computes it -- the others receive it through the communicator (a sum in which they contribute zeros: the one
+    // collective both back-ends have for this), so a node does not spend ranks x 0.7 s of CPU on identical work.
+    const int seg = std::max<int>(pgo::ORDER_SEGMENT, chain_len);
+    if (world == 1) {
+      PGOC(pgo::cached_pose_order(N, E, ia, ib, seg, &perm));
+    } else {
+      if (rank == 0) PGOC(pgo::cached_pose_order(N, E, ia, ib, seg, &perm));
+      else perm.assign((size_t)N, 0);
+      std::vector<double> tmp((size_t)N);
+      for (int32_t i = 0; i < N; ++i) tmp[i] = (double)perm[i];
+      double* d_tmp = nullptr;
+      HIPC(hipMalloc((void**)&d_tmp, (size_t)N * sizeof(double)));
+      HIPC(hipMemcpyAsync(d_tmp, tmp.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, stream));
+      int st_b = PGO_OK;
+      for (int64_t off = 0; off < N && st_b == PGO_OK; off += (1 << 16))   // 512 KiB pieces (a slot of the shm test back-end)
+        if (comm->allreduce(d_tmp + off, (int)std::min<int64_t>(N - off, 1 << 16), false, stream) != 0)
+          st_b = fail(PGO_ERR_COMM, "pose ordering: broadcast through the communicator failed");
+      if (st_b == PGO_OK && hipMemcpyAsync(tmp.data(), d_tmp, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess)
+        st_b = fail(PGO_ERR_HIP, "pose ordering: copy back");
+      if (st_b == PGO_OK && hipStreamSynchronize(stream) != hipSuccess) st_b = fail(PGO_ERR_HIP, "pose ordering: synchronise");
+      (void)hipFree(d_tmp);
+      PGOC(st_b);
+      for (int32_t i = 0; i < N; ++i) perm[i] = (int32_t)tmp[i];
+    }
     ia_p.resize(E);
     ib_p.resize(E);
     for (int32_t e = 0; e < E; ++e) {
@@ -637,8 +673,6 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   }
   PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, chain_len ? chain_len : grp_B, &S,
                                   tile_breaks_h.empty() ? nullptr : &tile_breaks_h));
-  HIPC(hipSetDevice(device));
-  HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   n_full = (int64_t)world * S.rows_per_rank;
   const int64_t EL = S.n_edges_local, NL = S.n_loc;
   inc_stride = ((S.n_inc + 63) / 64) * 64;  // whole 64-incidence groups (dev::hoff_index)
@@ -907,6 +941,15 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     if (const char* fm = PGO_EXP_ENV("PGO_FUSED_MAX_ROWS")) fused_max = atoll(fm);
     fused_p = knob("fused_p") != 0 && world == 1 && !force_collectives && !batch_mode && NL > 0 && NL <= fused_max;
     if (fused_p) PGOC(dalloc(&p_full2, dev::PS * n_full));
+  }
+  {
+    // One reduction point per PCG iteration instead of two (k_cg_sr_*): where the all-reduces are latency -- several ranks --
+    // and only in the inexact mode (pcg_rtol >= 1e-6: the recurrence for A p drifts over the thousands of iterations of
+    // the exact mode); needs the lean chain apply.  Test hook "single_reduction": 1 = also on one rank, 0 = never.
+    const long long kn = knob("single_reduction");
+    use_sr = chain_len > 0 && chain_chunk > 0 && !solo && !fused_p && !batch_mode && NL > 0 && opt.pcg_rtol >= 1e-6 &&
+             (kn == 1 || (kn != 0 && (world > 1 || force_collectives)));
+    if (use_sr) PGOC(dalloc(&sr_s, 3 * NL));
   }
   if (!fixed_mask_h.empty()) {
     PGOC(dalloc(&fixed_mask, (int64_t)fixed_mask_h.size()));
@@ -1414,10 +1457,30 @@ int pgo_handle::pcg(int* iters, double* rel) {
   else if (grouped) hipLaunchKernelGGL(dev::k_cg_init_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, (const double*)gs, part[0], part[1]);
   else hipLaunchKernelGGL(dev::k_cg_init, dim3(g_u1), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
   PGOC(check_launch("k_cg_init"));
-  PGOC(reduce_to_scal({{part[0], g_u1, 0}, {part[1], g_u1, 0}}, 4));
-  hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
-  PGOC(check_launch("k_cg_init_fin"));
-  if (!overlap) PGOC(share_gather_vector(p_full));
+  const bool sr = use_sr && chained;
+  // single-reduction loop: "make u visible to the peers, w = A u, reduce (gamma, rr, delta) together, new coefficients"
+  auto sr_product_and_scalars = [&](int first) -> int {
+    int n_sp = g_spmv;
+    const int32_t* done = first ? nullptr : &st->done;
+    if (overlap) PGOC(spmv_with_halo(p_full, ap, part[2], done, &n_sp));
+    else {
+      PGOC(share_gather_vector(p_full));
+      PGOC(spmv_enqueue(p_full, ap, part[2], 1, done));
+    }
+    PGOC(reduce_to_scal({{part[0], g_u1, 0}, {part[1], g_u1, 0}, {part[2], n_sp, 0}}, 4));
+    hipLaunchKernelGGL(dev::k_cg_sr_scal, dim3(1), dim3(1), 0, stream, st, (const double*)(scal + 4), opt.pcg_rtol, first);
+    return check_launch("k_cg_sr_scal");
+  };
+  if (sr) {
+    // the start-up kernel left u = M^-1 b in the gather vector (and in z, which becomes p: beta = 0 in the first update)
+    HIPC(hipMemsetAsync(sr_s, 0, (size_t)3 * S.n_loc * sizeof(double), stream));
+    PGOC(sr_product_and_scalars(1));
+  } else {
+    PGOC(reduce_to_scal({{part[0], g_u1, 0}, {part[1], g_u1, 0}}, 4));
+    hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
+    PGOC(check_launch("k_cg_init_fin"));
+    if (!overlap) PGOC(share_gather_vector(p_full));
+  }
   const int max_it = std::max(0, opt.pcg_max_iters);
   int every = std::max(1, opt.pcg_check_every);
   // one PCG iteration = 3 dependent launches; `par` is the r.z double-buffer parity baked into the arguments
@@ -1425,6 +1488,11 @@ int pgo_handle::pcg(int* iters, double* rel) {
   double* pbuf[2] = {p_full, p_full2};
   if (fused) HIPC(hipMemsetAsync(p_full2, 0, (size_t)dev::PS * n_full * sizeof(double), stream));  // "p_old" of iteration 0
   auto enqueue_iteration = [&](int par) -> int {
+    if (sr) {
+      launch_cg_sr_chain(V, part[0], part[1]);
+      PGOC(check_launch("k_cg_sr_cl"));
+      return sr_product_and_scalars(0);
+    }
     int n_sp = g_spmv;
     dev::CgVec Vi = V;
     if (fused) {
@@ -2242,6 +2310,7 @@ int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   out->direct_rank = h->direct ? h->dl_K : 0;
   out->direct_fallbacks = h->dl_fallbacks;
   out->direct_switched_at = h->dl_switched_at;
+  out->pcg_single_reduction = h->use_sr ? 1 : 0;
   return PGO_OK;
 }
 

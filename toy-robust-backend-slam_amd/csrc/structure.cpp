@@ -11,13 +11,29 @@
 //   Jacobian records), so assembly needs no communication at all.  An edge's cost
 //   is counted on the rank that owns its first endpoint Edge::a.
 #include <algorithm>
+#include <mutex>
 #include <numeric>
+#include <thread>
 #include <queue>
 #include <unordered_set>
 
 #include "pgo_internal.h"
 
 namespace pgo {
+
+// [0, n) in contiguous ranges over up to 8 host threads (large inputs only); f(begin, end)
+template <class F>
+static void parallel_ranges(int64_t n, F f) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int nt = (n < (1 << 16)) ? 1 : (int)std::min<unsigned>(8, hw ? hw : 1);
+  if (nt <= 1) {
+    f(0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t) pool.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
+  for (auto& th : pool) th.join();
+}
 
 // Locality ordering of the poses (see pgo_pose_order in pgo.h).
 int compute_pose_order(int32_t N, int32_t E, const int32_t* ia, const int32_t* ib, int32_t L, std::vector<int32_t>* perm) {
@@ -44,25 +60,35 @@ int compute_pose_order(int32_t N, int32_t E, const int32_t* ia, const int32_t* i
       adj_col[(size_t)fill[ia[e]]++] = ib[e];
       adj_col[(size_t)fill[ib[e]]++] = ia[e];
     }
-    for (int32_t i = 0; i < N; ++i) std::sort(adj_col.begin() + aptr[i], adj_col.begin() + aptr[(size_t)i + 1]);
+    parallel_ranges(N, [&](int64_t b, int64_t e) {
+      for (int64_t i = b; i < e; ++i) std::sort(adj_col.begin() + aptr[i], adj_col.begin() + aptr[(size_t)i + 1]);
+    });
   }
   auto has_edge = [&](int64_t x, int64_t y) {
     return std::binary_search(adj_col.begin() + aptr[x], adj_col.begin() + aptr[x + 1], (int32_t)y);
   };
   std::vector<std::pair<int32_t, int32_t>> seg_edges;
-  for (int32_t e = 0; e < E; ++e) {
-    const int64_t a = ia[e], b = ib[e];
-    const int32_t sa = (int32_t)(a / L), sb = (int32_t)(b / L);
-    if (sa == sb || sa >= n_full || sb >= n_full) continue;
-    bool ok = std::llabs(a - b) <= 1;
-    for (int da = -1; da <= 1 && !ok; ++da)
-      for (int db = -1; db <= 1 && !ok; ++db) {
-        if (da == 0 && db == 0) continue;
-        const int64_t x = a + da, y = b + db;
-        if (x < 0 || y < 0 || x >= N || y >= N || x == y) continue;
-        ok = has_edge(x, y);
+  {
+    std::mutex mu;
+    parallel_ranges(E, [&](int64_t e0, int64_t e1) {
+      std::vector<std::pair<int32_t, int32_t>> mine;
+      for (int64_t e = e0; e < e1; ++e) {
+        const int64_t a = ia[e], b = ib[e];
+        const int32_t sa = (int32_t)(a / L), sb = (int32_t)(b / L);
+        if (sa == sb || sa >= n_full || sb >= n_full) continue;
+        bool ok = std::llabs(a - b) <= 1;
+        for (int da = -1; da <= 1 && !ok; ++da)
+          for (int db = -1; db <= 1 && !ok; ++db) {
+            if (da == 0 && db == 0) continue;
+            const int64_t x = a + da, y = b + db;
+            if (x < 0 || y < 0 || x >= N || y >= N || x == y) continue;
+            ok = has_edge(x, y);
+          }
+        if (ok) mine.emplace_back(std::min(sa, sb), std::max(sa, sb));
       }
-    if (ok) seg_edges.emplace_back(std::min(sa, sb), std::max(sa, sb));
+      std::lock_guard<std::mutex> lk(mu);
+      seg_edges.insert(seg_edges.end(), mine.begin(), mine.end());   // (sorted and made unique below: the order does not matter)
+    });
   }
   std::sort(seg_edges.begin(), seg_edges.end());
   seg_edges.erase(std::unique(seg_edges.begin(), seg_edges.end()), seg_edges.end());
@@ -112,6 +138,38 @@ int compute_pose_order(int32_t N, int32_t E, const int32_t* ia, const int32_t* i
     const int32_t sgm = i / L;
     (*perm)[i] = sgm < n_full ? start_of[sgm] + (i - sgm * L) : i;
   }
+  return PGO_OK;
+}
+
+int cached_pose_order(int32_t N, int32_t E, const int32_t* ia, const int32_t* ib, int32_t L, std::vector<int32_t>* perm) {
+  struct Entry {
+    int32_t n = 0, e = 0, l = 0;
+    uint64_t h = 0;
+    std::vector<int32_t> perm;
+  };
+  static std::mutex mu;
+  static Entry cache[2];
+  static int next = 0;
+  uint64_t h = 1469598103934665603ull;   // FNV-1a over the endpoint words
+  for (int32_t e = 0; e < E; ++e) {
+    h = (h ^ (uint32_t)ia[e]) * 1099511628211ull;
+    h = (h ^ (uint32_t)ib[e]) * 1099511628211ull;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry& c : cache)
+      if (c.n == N && c.e == E && c.l == L && c.h == h && (int32_t)c.perm.size() == N) {
+        *perm = c.perm;
+        return PGO_OK;
+      }
+  }
+  int st = compute_pose_order(N, E, ia, ib, L, perm);
+  if (st != PGO_OK) return st;
+  std::lock_guard<std::mutex> lk(mu);
+  Entry& c = cache[next];
+  next ^= 1;
+  c.n = N; c.e = E; c.l = L; c.h = h;
+  c.perm = *perm;
   return PGO_OK;
 }
 
