@@ -196,7 +196,14 @@ typedef struct pgo_options {
                                       MIT, CSAIL, FR079 ...); with more (M3500, FRH: the dense Cholesky is no longer cheap) the
                                       solve starts with 1 and changes to 2 after an LM iteration whose PCG iteration count
                                       says PCG costs more than the direct solve (M3500 with DCS: yes, without: no); else 1      */
-  int32_t _pad_opt;
+  int32_t pcg_coarse_poses;    /* second preconditioner level: an additive coarse correction on the RIGID-BODY modes (translation x, y,
+                                  rotation about the centre) of aggregates of this many consecutive poses -- three unknowns per
+                                  aggregate, Galerkin matrix P'(J'J + D'D)P factorised densely per LM iteration (order <= 6143).
+                                  It removes the smooth long-range error that block-Jacobi cannot: M3500 METHOD 1, PCG to 1e-10:
+                                  1557 -> 178 iterations with 16-pose aggregates.  Rounded up to a multiple of the one-level
+                                  block (pcg_chain_len / pcg_block_poses).  One rank.  0 = off;
+                                  -1 (default) = auto: on in the exact mode (pcg_rtol <= 1e-4) for graphs of >= 512 poses that
+                                  stay on PCG, 16 poses per aggregate, doubled until the coarse order is <= 2400            */
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */
@@ -350,8 +357,11 @@ typedef struct pgo_handle_info {
   int32_t direct_fallbacks;          /* LM iterations whose direct solve gave no usable step and were redone by PCG  */
   int32_t direct_switched_at;        /* auto, rank above 2048: the LM iteration after which the direct solve took over from PCG
                                         (its PCG solve cost more than a direct solve of this rank does), 0 = it has not       */
+  int32_t pcg_coarse_poses;          /* resolved: poses per aggregate of the second preconditioner level, 0 = one level   */
+  int32_t pcg_coarse_rank;           /* order of its dense coarse matrix                                               */
   int32_t pcg_single_reduction;      /* 1 = the PCG loop with ONE reduction point per iteration (Chronopoulos-Gear recurrences:
                                         world > 1, pcg_rtol >= 1e-6, chain preconditioner), 0 = the textbook two-reduction loop */
+  int32_t _pad;
 } pgo_handle_info;
 int pgo_get_info(const pgo_t* h, pgo_handle_info* out);                           /* [host] */
 

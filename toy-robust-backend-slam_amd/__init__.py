@@ -63,7 +63,7 @@ class Options(C.Structure):
                 ("max_lm_diagonal", C.c_double), ("pcg_rtol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("pcg_check_every", C.c_int32), ("verbose", C.c_int32),
                 ("use_graphs", C.c_int32), ("pcg_block_poses", C.c_int32), ("halo_exchange", C.c_int32), ("sc_prior_lambda", C.c_double), ("pose_ordering", C.c_int32), ("info_weighting", C.c_int32),
-                ("pcg_chain_len", C.c_int32), ("halo_overlap", C.c_int32), ("linear_solver", C.c_int32), ("_pad_opt", C.c_int32)]
+                ("pcg_chain_len", C.c_int32), ("halo_overlap", C.c_int32), ("linear_solver", C.c_int32), ("pcg_coarse_poses", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -104,7 +104,8 @@ class HandleInfo(C.Structure):
                 ("chain_kernel", C.c_int32), ("pose_ordering", C.c_int32), ("halo_exchange", C.c_int32),
                 ("halo_overlap", C.c_int32), ("halo_send_rows", C.c_int64), ("halo_recv_rows", C.c_int64),
                 ("device_bytes", C.c_int64), ("host_enqueue_us_per_pcg_iter", C.c_double), ("pcg_graph_replay", C.c_int32),
-                ("linear_solver", C.c_int32), ("direct_rank", C.c_int32), ("direct_fallbacks", C.c_int32), ("direct_switched_at", C.c_int32), ("pcg_single_reduction", C.c_int32)]
+                ("linear_solver", C.c_int32), ("direct_rank", C.c_int32), ("direct_fallbacks", C.c_int32), ("direct_switched_at", C.c_int32), ("pcg_coarse_poses", C.c_int32), ("pcg_coarse_rank", C.c_int32),
+                ("pcg_single_reduction", C.c_int32), ("_pad", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -29,6 +29,7 @@
 #include "kernels.hip.h"
 #include "solo.hip.h"
 #include "direct.hip.h"
+#include "coarse.hip.h"
 #include "pgo_internal.h"
 
 using pgo::fail;
@@ -114,6 +115,14 @@ struct pgo_handle {
   double *hoff = nullptr, *hd = nullptr, *gs = nullptr, *d2 = nullptr, *minv = nullptr, *hdd = nullptr;
   // CG
   double *y = nullptr, *r = nullptr, *z = nullptr, *ap = nullptr, *p_full = nullptr;
+  // second preconditioner level (coarse.hip.h): additive coarse correction on the rigid-body modes of pose aggregates
+  bool use_coarse = false;
+  int co_agg = 0, co_nagg = 0, co_K = 0, co_Kp = 0, co_ncb = 0;
+  double *co_pb = nullptr, *co_cap = nullptr, *co_nm = nullptr, *co_dwork = nullptr, *co_rc = nullptr, *co_cy = nullptr, *co_ec = nullptr;
+  int32_t *co_cb_i = nullptr, *co_cb_j = nullptr, *co_cb_ptr = nullptr, *co_cb_q = nullptr, *co_cb_row = nullptr;
+  int coarse_setup();      // create: aggregates, coarse block lists, buffers
+  int coarse_factor();     // per LM iteration: basis, Galerkin matrix, Cholesky + inverse factor
+  int coarse_apply(double* p_or_null, double* extra_rz, const int32_t* done);   // z += P (P'(H + D'D)P)^-1 P' r
   // single-reduction PCG loop (k_cg_sr_*: one all-reduce per iteration; several ranks, inexact mode, chain preconditioner)
   bool use_sr = false;
   double* sr_s = nullptr;   // s = A p, carried by recurrence
@@ -957,7 +966,163 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   }
   if (batch_mode) PGOC(dalloc(&edge_cost, std::max<int64_t>(EL, 1)));
   PGOC(direct_setup(N));
+  PGOC(coarse_setup());   // (after the direct solver's decision: auto adds the coarse level only to solves that stay on PCG)
   return sync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Second preconditioner level (coarse.hip.h).  opt.pcg_coarse_poses: 0 = off, > 0 = poses per aggregate, -1 = auto.
+namespace {
+constexpr int COARSE_MAX_RANK = 6144;   // order of the dense coarse matrix (k_chol_panel's range)
+}
+int pgo_handle::coarse_setup() {
+  const int world = comm ? comm->world : 1;
+  const int64_t NL = S.n_loc;
+  int want = opt.pcg_coarse_poses;
+  if (want == 0) return PGO_OK;
+  const int unit = chain_len ? chain_len : grp_B;   // aggregates are unions of the one-level blocks
+  auto no = [&](const std::string& why) -> int {
+    if (want > 0) return fail(PGO_ERR_UNSUPPORTED, "pcg_coarse_poses: " + why);
+    return PGO_OK;
+  };
+  if (world != 1 || force_collectives) return no("one rank only");
+  if (batch_mode) return no("not inside a batched handle");
+  if (NL < 2) return PGO_OK;
+  if (want < 0) {
+    // auto: the exact mode of graphs that stay on PCG (the direct solve, where it applies cheaply, is faster still).
+    // Aggregates of 16 poses up to ~10k poses (M3500: rank 657), growing so that the coarse matrix stays below rank ~2400
+    // (its Cholesky is paid once per LM iteration, its two dense products once per PCG iteration)
+    if (!(opt.pcg_rtol <= 1e-4) || direct || NL < 512) return PGO_OK;
+    want = 16;
+    while (3 * ((NL + want - 1) / want) > 2400) want *= 2;
+  }
+  if (want % unit != 0) want = ((want + unit - 1) / unit) * unit;
+  co_agg = want;
+  co_nagg = (int)((NL + co_agg - 1) / co_agg);
+  co_K = 3 * co_nagg;
+  if (co_K + 1 > COARSE_MAX_RANK) return no("the coarse matrix would have order " + std::to_string(co_K) + " (at most " + std::to_string(COARSE_MAX_RANK - 1) + ")");
+  co_Kp = ((co_K + dev::CHOL_NB - 1) / dev::CHOL_NB) * dev::CHOL_NB;
+  // coarse blocks and their fine entries: incidences sorted by (aggregate of the row, aggregate of the column, position)
+  std::vector<uint64_t> key((size_t)S.n_inc);
+  {
+    size_t k = 0;
+    for (int32_t r = 0; r < S.n_loc; ++r)
+      for (int32_t q = S.inc_ptr[r]; q < S.inc_ptr[r + 1]; ++q) {
+        const uint64_t I = (uint64_t)(r / co_agg), J = (uint64_t)((S.inc_col[q] - S.lo) / co_agg);
+        key[k++] = ((I * (uint64_t)co_nagg + J) << 32) | (uint32_t)q;
+      }
+  }
+  std::sort(key.begin(), key.end());
+  std::vector<int32_t> row_of((size_t)S.n_inc);
+  for (int32_t r = 0; r < S.n_loc; ++r)
+    for (int32_t q = S.inc_ptr[r]; q < S.inc_ptr[r + 1]; ++q) row_of[q] = r;
+  std::vector<int32_t> cbi, cbj, cbp, cbq((size_t)S.n_inc), cbr((size_t)S.n_inc);
+  {
+    size_t k = 0;
+    int next_diag = 0;   // every aggregate gets its (I, I) block, also without an off-diagonal fine entry inside
+    auto open_block = [&](int I, int J) {
+      cbi.push_back(I);
+      cbj.push_back(J);
+      cbp.push_back((int32_t)k);
+    };
+    while (k < key.size() || next_diag < co_nagg) {
+      const uint64_t blk = k < key.size() ? (key[k] >> 32) : ~0ull;
+      const uint64_t dblk = next_diag < co_nagg ? (uint64_t)next_diag * co_nagg + next_diag : ~0ull;
+      if (dblk < blk) {   // a diagonal block without fine off-diagonal entries
+        open_block(next_diag, next_diag);
+        ++next_diag;
+        continue;
+      }
+      if (dblk == blk) ++next_diag;
+      open_block((int)(blk / co_nagg), (int)(blk % co_nagg));
+      while (k < key.size() && (key[k] >> 32) == blk) {
+        const int32_t q = (int32_t)(key[k] & 0xffffffffu);
+        cbq[k] = q;
+        cbr[k] = row_of[q];
+        ++k;
+      }
+    }
+    cbp.push_back((int32_t)k);
+  }
+  co_ncb = (int)cbi.size();
+  PGOC(dalloc(&co_pb, 5 * NL));
+  PGOC(dalloc(&co_cap, (int64_t)co_Kp * co_Kp));
+  PGOC(dalloc(&co_nm, (int64_t)co_Kp * co_Kp));
+  PGOC(dalloc(&co_dwork, (int64_t)(co_Kp / 32) * 1024));
+  PGOC(dalloc(&co_rc, co_Kp));
+  PGOC(dalloc(&co_cy, co_Kp));
+  PGOC(dalloc(&co_ec, co_Kp));
+  PGOC(dalloc(&co_cb_i, co_ncb));
+  PGOC(dalloc(&co_cb_j, co_ncb));
+  PGOC(dalloc(&co_cb_ptr, co_ncb + 1));
+  PGOC(dalloc(&co_cb_q, std::max<int64_t>(1, S.n_inc)));
+  PGOC(dalloc(&co_cb_row, std::max<int64_t>(1, S.n_inc)));
+  PGOC(upload(co_cb_i, cbi));
+  PGOC(upload(co_cb_j, cbj));
+  PGOC(upload(co_cb_ptr, cbp));
+  PGOC(upload(co_cb_q, cbq));
+  PGOC(upload(co_cb_row, cbr));
+  PGOC(sync());   // the host lists die with this scope
+  HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_chol_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::CHOL_LDS_BYTES));
+  use_coarse = true;
+  if (opt.linear_solver == 0) dl_possible = false;   // (ranks above the direct solve's cheap range: two-level PCG instead of the PCG / direct alternation)
+  // the loops that fold launches together assume the one-level preconditioner: two-level solves take the plain three-kernel loop
+  solo = false;
+  fused_p = false;
+  use_sr = false;
+  return PGO_OK;
+}
+
+int pgo_handle::coarse_factor() {
+  dev::CoarseArgs A;
+  A.n_loc = S.n_loc;
+  A.agg = co_agg;
+  A.n_agg = co_nagg;
+  A.K = co_K;
+  A.Kp = co_Kp;
+  A.poses = poses;
+  A.scale = scale;
+  A.pb = co_pb;
+  A.hoff = hoff;
+  A.hd = hd;
+  A.d2 = d2;
+  A.inc_col = inc_col;
+  A.cb_i = co_cb_i;
+  A.cb_j = co_cb_j;
+  A.cb_ptr = co_cb_ptr;
+  A.cb_q = co_cb_q;
+  A.cb_row = co_cb_row;
+  A.n_cb = co_ncb;
+  A.cap = co_cap;
+  A.dwork = co_dwork;
+  hipLaunchKernelGGL(dev::k_coarse_basis, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, A);
+  PGOC(check_launch("k_coarse_basis"));
+  HIPC(hipMemsetAsync(co_cap, 0, (size_t)co_Kp * co_Kp * sizeof(double), stream));
+  HIPC(hipMemsetAsync(co_dwork, 0, (size_t)(co_Kp / 32) * 1024 * sizeof(double), stream));
+  hipLaunchKernelGGL(dev::k_coarse_assemble, dim3((co_ncb + 3) / 4), dim3(256), 0, stream, A);
+  PGOC(check_launch("k_coarse_assemble"));
+  if (co_Kp > co_K) {
+    hipLaunchKernelGGL(dev::k_coarse_pad, dim3(1), dim3(32), 0, stream, co_cap, co_dwork, co_K, co_Kp);
+    PGOC(check_launch("k_coarse_pad"));
+  }
+  const int nb = co_Kp / 32;
+  for (int kb = 0; kb < nb; ++kb) {
+    hipLaunchKernelGGL(dev::k_chol_panel, dim3(std::max(1, nb - 1)), dim3(dev::CHOL_THREADS), dev::CHOL_LDS_BYTES, stream, co_cap, co_nm, co_dwork, co_Kp, nb, kb);
+    PGOC(check_launch("k_chol_panel (coarse level)"));
+  }
+  return PGO_OK;
+}
+
+int pgo_handle::coarse_apply(double* p_or_null, double* extra_rz, const int32_t* done) {
+  const int nb = co_Kp / 32;
+  hipLaunchKernelGGL(dev::k_coarse_restrict, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, (int)S.n_loc, co_agg, co_nagg, (const double*)co_pb,
+                     (const double*)r, co_rc, done);
+  hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_rc, co_cy, 0);
+  hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_cy, co_ec, 1);
+  const int g = (int)std::min<int64_t>((S.n_loc + 255) / 256, 512);
+  hipLaunchKernelGGL(dev::k_coarse_prolong, dim3(g), dim3(256), 0, stream, (int)S.n_loc, co_agg, co_K, (const double*)co_pb, (const double*)co_rc,
+                     (const double*)co_ec, z, p_or_null, extra_rz, done);
+  return check_launch("coarse level apply");
 }
 
 // evaluate (K1, unscaled records) + assemble (K2, applies the current `scale`) at `poses`;
@@ -1476,7 +1641,10 @@ int pgo_handle::pcg(int* iters, double* rel) {
     HIPC(hipMemsetAsync(sr_s, 0, (size_t)3 * S.n_loc * sizeof(double), stream));
     PGOC(sr_product_and_scalars(1));
   } else {
-    PGOC(reduce_to_scal({{part[0], g_u1, 0}, {part[1], g_u1, 0}}, 4));
+    // two levels: z (= p) of the start-up kernel gets the coarse correction, r.z one more partial
+    const int n_rz0 = use_coarse ? g_u1 + 1 : g_u1;
+    if (use_coarse) PGOC(coarse_apply(p_full + dev::PS * (int64_t)S.lo, part[0] + g_u1, nullptr));
+    PGOC(reduce_to_scal({{part[0], n_rz0, 0}, {part[1], g_u1, 0}}, 4));
     hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
     PGOC(check_launch("k_cg_init_fin"));
     if (!overlap) PGOC(share_gather_vector(p_full));
@@ -1519,6 +1687,11 @@ int pgo_handle::pcg(int* iters, double* rel) {
     else hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, par, pap, n_pap, part[1], part[2]);
     PGOC(check_launch("k_cg_update1"));
     if (fused) return PGO_OK;  // its r.z / r.r partials are booked by the next SpMV, or by k_cg_book at the end of the slice
+    if (use_coarse) {   // second level: z += P e_c, its share of r.z as one more partial (single rank)
+      PGOC(coarse_apply(nullptr, part[1] + g_u1, &st->done));
+      hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_u1 + 1, part[2], g_u1);
+      return check_launch("k_cg_update2");
+    }
     if (multi) {
       PGOC(reduce_to_scal({{part[1], g_u1, 0}, {part[2], g_u1, 0}}, 7));
       hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
@@ -1727,6 +1900,7 @@ int pgo_handle::prepare_preconditioner() {
     PGOC(check_launch("k_prepare_groups"));
   }
   if (chain_len) PGOC(factor_chain());
+  if (use_coarse) PGOC(coarse_factor());
   return PGO_OK;
 }
 
@@ -2008,6 +2182,7 @@ void pgo_options_default(pgo_options* o) {
                          // that check itself when it runs on several GPUs and then times the verified p2p path)
   o->halo_overlap = 0;   // opt-in: the two-stream schedule has never run against a real peer (no multi-GPU lease yet)
   o->linear_solver = 0;  // auto: the direct chain + low-rank solve on small chain-like graphs in the exact mode, else PCG
+  o->pcg_coarse_poses = -1;  // auto: a rigid-body coarse level for exact-mode PCG solves of graphs of >= 512 poses
 }
 
 int pgo_create(pgo_t** h, int32_t n_poses, const double* poses, int32_t n_edges, const int32_t* ia, const int32_t* ib,
@@ -2311,6 +2486,8 @@ int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   out->direct_fallbacks = h->dl_fallbacks;
   out->direct_switched_at = h->dl_switched_at;
   out->pcg_single_reduction = h->use_sr ? 1 : 0;
+  out->pcg_coarse_poses = h->use_coarse ? h->co_agg : 0;
+  out->pcg_coarse_rank = h->use_coarse ? h->co_K : 0;
   return PGO_OK;
 }
 
@@ -2815,6 +2992,7 @@ int pgo_debug_precond(pgo_t* h, const double* r_in, double* z_out) {
     hipLaunchKernelGGL(dev::k_cg_init, dim3(h->g_vec), dim3(dev::WG), 0, h->stream, V, (const double*)h->ap, h->part[0], h->part[1]);
   }
   PGOC(h->check_launch("k_cg_init (debug)"));
+  if (h->use_coarse) PGOC(h->coarse_apply(nullptr, h->part[0] + 2048, nullptr));   // the second level's share of z
   std::vector<double> ztmp((size_t)3 * N);
   HIPC(hipMemcpyAsync(ztmp.data(), h->z, ztmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PGOC(h->sync());
