@@ -19,8 +19,11 @@
 // Per LM iteration: centres + basis planes (k_coarse_basis), the Galerkin matrix P'(H + D'D)P, dense, order 3 x aggregates,
 // every 3x3 block summed by one wavefront in a fixed order (k_coarse_assemble: no atomics, bitwise reproducible), its
 // Cholesky factorisation with the explicit inverse factor N = L^-1 (k_chol_panel of direct.hip.h, fp64 matrix cores).
-// Per PCG iteration: r_c = P'r (k_coarse_restrict), e_c = N'(N r_c) (two dense products, k_tri_apply), z += P e_c and the
-// one extra partial r_c . e_c of r.z (k_coarse_prolong).
+// Per PCG iteration: r_c = P'r (k_coarse_restrict); e_c = A_c^-1 r_c -- one product with the explicit inverse N'N where the
+// coarse order is small (k_coarse_matvec, order <= 1024), else the two triangular products N'(N r_c) (k_tri_apply) -- with
+// the partials of r_c . e_c, the coarse level's share of r.z; and the prolongation folded into the direction update,
+// p = (z + P e_c) + beta p (k_cg_update2c).  A factorisation that lost positive definiteness to rounding switches the
+// level off for that LM iteration (k_coarse_check: a device flag every apply kernel reads).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -194,33 +197,10 @@ __global__ __launch_bounds__(256) void k_coarse_restrict(int n_loc, int agg, int
   }
 }
 
-// z += P e_c (and the same into the owned rows of the gather vector when p != nullptr: the PCG start-up, where p = z);
-// workgroup 0 also writes the coarse part of r.z = r_c . e_c as ONE more partial (extra_rz[0]) in a fixed order.
-// A non-finite coarse solution (a coarse matrix that lost positive definiteness to rounding) is dropped as a whole.
-__global__ __launch_bounds__(256) void k_coarse_prolong(int n_loc, int agg, int K, const double* __restrict__ pb,
-                                                        const double* __restrict__ rc, const double* __restrict__ ec,
-                                                        double* __restrict__ z, double* __restrict__ p, double* __restrict__ extra_rz,
-                                                        const int32_t* __restrict__ done) {
-  __shared__ double red[8];
-  __shared__ int bad;
-  if (done && *done) return;
-  if (threadIdx.x == 0) bad = 0;
-  __syncthreads();
-  // every workgroup takes the same decision from the same K values (K <= 6144: L2-resident)
-  double dot = 0.0;
-  int nonfinite = 0;
-  for (int k = threadIdx.x; k < K; k += 256) {
-    const double e = ec[k];
-    nonfinite |= !isfinite(e);
-    dot += rc[k] * e;
-  }
-  if (nonfinite) bad = 1;
-  dot = block_sum_bcast(dot, red);   // (contains barriers: `bad` is visible afterwards)
-  if (bad) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) extra_rz[0] = 0.0;
-    return;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) extra_rz[0] = dot;
+// z += P e_c and the same into the gather vector p (the PCG start-up, where p = z); skipped as a whole when the level is off
+__global__ __launch_bounds__(256) void k_coarse_prolong(int n_loc, int agg, const double* __restrict__ pb, const double* __restrict__ ec,
+                                                        double* __restrict__ z, double* __restrict__ p, const int32_t* __restrict__ ok) {
+  if (!*ok) return;
   const int64_t n = n_loc;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n_loc; i += gridDim.x * 256) {
     const PBasis b = pb_load(pb, n, i);
@@ -237,6 +217,107 @@ __global__ __launch_bounds__(256) void k_coarse_prolong(int n_loc, int agg, int 
       pp[1] += z1;
       pp[2] += z2;
     }
+  }
+}
+
+__global__ void k_fill(double* __restrict__ x, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
+// explicit inverse of the coarse matrix, Ainv = N'N (N = L^-1, lower triangular), for small orders: one thread per entry
+__global__ __launch_bounds__(256) void k_coarse_ainv(const double* __restrict__ Nm, int Kp, double* __restrict__ Ainv) {
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= Kp) return;
+  double s = 0.0;
+  for (int k = max(i, j); k < Kp; ++k) s += Nm[(int64_t)k * Kp + i] * Nm[(int64_t)k * Kp + j];
+  Ainv[(int64_t)i * Kp + j] = s;
+}
+
+// the level is usable iff a probe of the factor is finite: x = Ainv 1 (explicit inverse) or x = N'(N 1) computed by the
+// caller with k_tri_apply; one workgroup
+__global__ __launch_bounds__(256) void k_coarse_check(const double* __restrict__ x, int K, int32_t* __restrict__ ok) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  int nf = 0;
+  for (int k = threadIdx.x; k < K; k += 256) nf |= !isfinite(x[k]);
+  if (nf) bad = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) *ok = bad ? 0 : 1;
+}
+
+// e_c = Ainv r_c (dense, symmetric, order Kp <= 1024): one wavefront per row, four rows per workgroup; the workgroup's
+// share of r_c . e_c goes to dot_part[blockIdx.x] (fixed order).  Level off: e_c = 0, partials 0.
+__global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict__ Ainv, int Kp, const double* __restrict__ rc,
+                                                       double* __restrict__ ec, double* __restrict__ dot_part,
+                                                       const int32_t* __restrict__ ok, const int32_t* __restrict__ done) {
+  __shared__ double sh[4];
+  if (done && *done) return;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  double s = 0.0;
+  if (*ok && row < Kp) {
+    const double* a = Ainv + (int64_t)row * Kp;
+    for (int c = lane; c < Kp; c += 64) s += a[c] * rc[c];
+  }
+  s = wave_sum_fixed(s);
+  if (lane == 0) {
+    if (row < Kp) ec[row] = s;
+    sh[w] = (row < Kp) ? s * rc[row] : 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) dot_part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// large orders, after the two triangular products: partials of r_c . e_c, 256 entries per workgroup; level off: e_c = 0
+__global__ __launch_bounds__(256) void k_coarse_dot(int Kp, const double* __restrict__ rc, double* __restrict__ ec,
+                                                    double* __restrict__ dot_part, const int32_t* __restrict__ ok,
+                                                    const int32_t* __restrict__ done) {
+  __shared__ double red[8];
+  if (done && *done) return;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  double v = 0.0;
+  if (k < Kp) {
+    if (!*ok) ec[k] = 0.0;
+    else v = rc[k] * ec[k];
+  }
+  v = block_sum_bcast(v, red);
+  if (threadIdx.x == 0) dot_part[blockIdx.x] = v;
+}
+
+// k_cg_update2 with the prolongation folded in: beta = rz_new / rz ; p = (z + P e_c) + beta p, where rz_new sums the
+// one-level partials AND the coarse level's partials of r_c . e_c (n_rz covers both).  Workgroup 0 publishes the scalars.
+__global__ __launch_bounds__(WG) void k_cg_update2c(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
+                                                    const double* __restrict__ part_rr, int n_rr, int agg,
+                                                    const double* __restrict__ pb, const double* __restrict__ ec) {
+  __shared__ double red[8];
+  if (V.st->done) return;
+  const double rz_new = sum_partials_bcast(part_rz, n_rz, red);
+  const double rr = sum_partials_bcast(part_rr, n_rr, red);
+  const double rz_old = V.st->rz[parity];
+  const double tol2 = V.st->tol2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    V.st->rz[parity ^ 1] = rz_new;
+    V.st->rr = rr;
+    V.st->iters += 1;
+  }
+  if (rr <= tol2) {  // converged: leave p alone, freeze the solve (same decision in every workgroup)
+    if (blockIdx.x == 0 && threadIdx.x == 0) V.st->done = 1;
+    return;
+  }
+  const double beta = rz_new / rz_old;
+  const int64_t n = V.n_loc;
+  double* p = V.p + PS * (int64_t)V.lo;
+  for (int i = blockIdx.x * WG + threadIdx.x; i < V.n_loc; i += gridDim.x * WG) {
+    const PBasis b = pb_load(pb, n, i);
+    const int I = i / agg;
+    const double e0 = ec[3 * I], e1 = ec[3 * I + 1], e2 = ec[3 * I + 2];
+    const double* zz = V.z + 3 * (int64_t)i;
+    double* pp = p + PS * (int64_t)i;
+    pp[0] = (zz[0] + (b.a0 * e0 + b.b0 * e2)) + beta * pp[0];
+    pp[1] = (zz[1] + (b.a1 * e1 + b.b1 * e2)) + beta * pp[1];
+    pp[2] = (zz[2] + b.a2 * e2) + beta * pp[2];
   }
 }
 

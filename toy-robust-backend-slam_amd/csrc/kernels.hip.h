@@ -467,6 +467,8 @@ struct AsmArgs {
   const int32_t* inc_edge;   // (local edge << 1) | side
   const int32_t* inc_col;    // global pose position of the other endpoint
   const int32_t* tile_row;   // n_tiles + 1 (local rows)
+  const uint8_t* inc_rowoff; // row of the incidence - first row of its tile
+  const int4* tile_desc;     // per tile {first local row, rows, first incidence, incidences} (shared with K3)
   const double* scale;       // [.. x 3] Jacobi column scales, global pose positions (0 on the constant pose)
   int32_t n_tiles;
   int32_t n_loc;
@@ -494,137 +496,186 @@ struct AsmArgs {
 // (9 doubles, staged in LDS).  Phase B: one thread per (row, component) sums its
 // row's staged contributions in incidence order -- a fixed order, so the result is
 // bitwise reproducible and independent of the sharding.
+// Everything one incidence contributes: the off-diagonal block (stored), the chain record's C part, and the nine (SC:
+// fifteen) staged values of its row's diagonal block / gradient.  ed = (local edge << 1) | side.
+template <bool SC, bool INFO>
+__device__ __forceinline__ void asm_incidence(const AsmArgs& A, int q, int ed, int64_t col, int row, bool first_of_pair, int tid,
+                                              double (*scr)[WG]) {
+  constexpr int RN = RecLayout<INFO>::N, R0 = RecLayout<INFO>::R0;
+  const double2* rp = reinterpret_cast<const double2*>(A.jr + (int64_t)(ed >> 1) * RN);
+  double R[RN];
+#pragma unroll
+  for (int k = 0; k < RN / 2; ++k) {
+    const double2 v = rp[k];
+    R[2 * k] = v.x;
+    R[2 * k + 1] = v.y;
+  }
+  // Jacobi column scales of this row's pose and of the other endpoint
+  double ss[3], so[3];
+  {
+    const double* s_self = A.scale + 3 * (int64_t)(A.lo + row);
+    const double* s_oth = A.scale + 3 * col;
+    ss[0] = s_self[0]; ss[1] = s_self[1]; ss[2] = s_self[2];
+    so[0] = s_oth[0]; so[1] = s_oth[1]; so[2] = s_oth[2];
+  }
+  // S[k*3+a] = d e_k / d (self pose)_a * scale, O likewise for the other endpoint.
+  // side 0: self = P1 (block A), other = P2 (implied block); side 1: the reverse.
+  double S[9], O[9];
+  const bool self_is_a = (ed & 1) == 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double a0 = R[3 * k], a1 = R[3 * k + 1], a2 = R[3 * k + 2];
+    const double b2 = INFO ? R[9 + k] : ((k == 2) ? R[9] : 0.0);
+    const double x0 = self_is_a ? a0 : -a0, x1 = self_is_a ? a1 : -a1, x2 = self_is_a ? a2 : b2;
+    const double y0 = self_is_a ? -a0 : a0, y1 = self_is_a ? -a1 : a1, y2 = self_is_a ? b2 : a2;
+    S[3 * k] = x0 * ss[0]; S[3 * k + 1] = x1 * ss[1]; S[3 * k + 2] = x2 * ss[2];
+    O[3 * k] = y0 * so[0]; O[3 * k + 1] = y1 * so[1]; O[3 * k + 2] = y2 * so[2];
+  }
+  // METHOD 2: elimination coefficients of this edge's switch (c == 0 for ordinary edges)
+  double cc = 0.0, gam = 0.0, vs[3] = {0.0, 0.0, 0.0}, vo[3] = {0.0, 0.0, 0.0};
+  if constexpr (SC) {
+    const int64_t le = ed >> 1;
+    cc = A.sw_c[le];
+    if (cc != 0.0) {
+      const double* j = A.sw_js + 3 * le;
+      gam = A.sw_gamma[le];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        vs[a] = S[a] * j[0] + S[3 + a] * j[1] + S[6 + a] * j[2];
+        vo[a] = O[a] * j[0] + O[3 + a] * j[1] + O[6 + a] * j[2];
+      }
+    }
+  }
+  double HB[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      double v = S[a] * O[b] + S[3 + a] * O[3 + b] + S[6 + a] * O[6 + b];
+      if constexpr (SC) v -= cc * vs[a] * vo[b];  // J'(I - c j j')J
+      HB[3 * a + b] = v;
+    }
+  hoff_store(A.hoff, q, HB);
+  // chain preconditioner: the block (i, i-1) goes straight into the factorisation's input record (C part), so that
+  // no kernel has to dig it out of the AoSoA block stream again (k_chain_extract read 975 MB to find 72 MB).  With
+  // several edges between i-1 and i the first incidence writes and k_chain_dupfix replaces it by the ordered sum.
+  if (A.chain_rec != nullptr && col == (int64_t)A.lo + row - 1 && (row % A.chain_seg) != 0 && first_of_pair) {
+    double2* o = reinterpret_cast<double2*>(A.chain_rec + (int64_t)row * CHAIN_REC + 6);
+    o[0] = make_double2(HB[0], HB[1]);
+    o[1] = make_double2(HB[2], HB[3]);
+    o[2] = make_double2(HB[4], HB[5]);
+    o[3] = make_double2(HB[6], HB[7]);
+    A.chain_rec[(int64_t)row * CHAIN_REC + 14] = HB[8];
+  }
+  double d0 = S[0] * S[0] + S[3] * S[3] + S[6] * S[6], d1 = S[0] * S[1] + S[3] * S[4] + S[6] * S[7];
+  double d2 = S[0] * S[2] + S[3] * S[5] + S[6] * S[8], d3 = S[1] * S[1] + S[4] * S[4] + S[7] * S[7];
+  double d4 = S[1] * S[2] + S[4] * S[5] + S[7] * S[8], d5 = S[2] * S[2] + S[5] * S[5] + S[8] * S[8];
+  double g0 = S[0] * R[R0] + S[3] * R[R0 + 1] + S[6] * R[R0 + 2], g1 = S[1] * R[R0] + S[4] * R[R0 + 1] + S[7] * R[R0 + 2];
+  double g2 = S[2] * R[R0] + S[5] * R[R0 + 1] + S[8] * R[R0 + 2];
+  if constexpr (SC) {
+    scr[9][tid] = d0;  scr[10][tid] = d3; scr[11][tid] = d5;   // unreduced diagonal and gradient
+    scr[12][tid] = g0; scr[13][tid] = g1; scr[14][tid] = g2;
+    d0 -= cc * vs[0] * vs[0]; d1 -= cc * vs[0] * vs[1]; d2 -= cc * vs[0] * vs[2];
+    d3 -= cc * vs[1] * vs[1]; d4 -= cc * vs[1] * vs[2]; d5 -= cc * vs[2] * vs[2];
+    g0 -= gam * vs[0]; g1 -= gam * vs[1]; g2 -= gam * vs[2];  // J'(r - gamma j)
+  }
+  scr[0][tid] = d0; scr[1][tid] = d1; scr[2][tid] = d2; scr[3][tid] = d3; scr[4][tid] = d4; scr[5][tid] = d5;
+  scr[6][tid] = g0; scr[7][tid] = g1; scr[8][tid] = g2;
+}
+
+template <bool SC>
+__device__ __forceinline__ void asm_store_row(const AsmArgs& A, int c, int row, double s) {
+  if (c < 6) {
+    A.hd[(int64_t)c * A.n_loc + row] = s;
+  } else if (c < 9) {
+    A.gs[3 * (int64_t)row + (c - 6)] = s;
+  } else if (c < 12) {
+    A.diag_full[3 * (int64_t)row + (c - 9)] = s;
+  } else {
+    A.gs_full[3 * (int64_t)row + (c - 12)] = s;
+  }
+}
+
+// Plain tiles (<= 256 incidences, the rule) run as a two-stage pipeline like K3: the tile's descriptor is ONE 16-byte
+// record, the index triples (edge | column | row offset) of tile t + 1 are requested while tile t is computed, the tile's
+// row pointers wait in LDS for the row phase, and the staging area is double-buffered (one barrier per tile).  Before,
+// a tile cost four dependent round trips (tile_row -> inc_ptr -> inc_edge -> record, plus an 8-step search for the row)
+// and two barriers: 433 us at 1M poses for 1.83 GB of traffic.
 template <bool SC, bool INFO>
 __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
   static_assert(!(SC && INFO), "switchable constraints have no information-weighted form here");
-  constexpr int RN = RecLayout<INFO>::N, R0 = RecLayout<INFO>::R0;
   constexpr int NS = SC ? 15 : 9;  // staged values per incidence
-  __shared__ double scr[NS][WG];
+  __shared__ double scr[2][NS][WG];
+  __shared__ int sptr[2][WG + 1];
   const int tid = threadIdx.x;
   const XcdRange xr = xcd_range(A.n_tiles);
-  for (int t = xr.begin; t < xr.end; t += xr.step) {
-    const int r0 = A.tile_row[t], r1 = A.tile_row[t + 1];
-    const int nrows = r1 - r0;
-    const int q0 = A.inc_ptr[r0], q1 = A.inc_ptr[r1];
-    double acc = 0.0;  // used only by the single-row multi-chunk case (tid < 9)
-    const bool multi = (q1 - q0) > WG;
-    for (int base = q0; base < q1 || base == q0; base += WG) {
-      const int q = base + tid;
-      if (q < q1) {
-        const int ed = A.inc_edge[q];
-        const int64_t col = A.inc_col[q];
-        const double2* rp = reinterpret_cast<const double2*>(A.jr + (int64_t)(ed >> 1) * RN);
-        double R[RN];
-#pragma unroll
-        for (int k = 0; k < RN / 2; ++k) {
-          const double2 v = rp[k];
-          R[2 * k] = v.x;
-          R[2 * k + 1] = v.y;
-        }
-        // Jacobi column scales of this row's pose and of the other endpoint
-        double ss[3], so[3];
-        const int row = (int)(upper_row(A.inc_ptr, r0, r1, q));
-        {
-          const double* s_self = A.scale + 3 * (int64_t)(A.lo + row);
-          const double* s_oth = A.scale + 3 * col;
-          ss[0] = s_self[0]; ss[1] = s_self[1]; ss[2] = s_self[2];
-          so[0] = s_oth[0]; so[1] = s_oth[1]; so[2] = s_oth[2];
-        }
-        // S[k*3+a] = d e_k / d (self pose)_a * scale, O likewise for the other endpoint.
-        // side 0: self = P1 (block A), other = P2 (implied block); side 1: the reverse.
-        double S[9], O[9];
-        const bool self_is_a = (ed & 1) == 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double a0 = R[3 * k], a1 = R[3 * k + 1], a2 = R[3 * k + 2];
-          const double b2 = INFO ? R[9 + k] : ((k == 2) ? R[9] : 0.0);
-          const double x0 = self_is_a ? a0 : -a0, x1 = self_is_a ? a1 : -a1, x2 = self_is_a ? a2 : b2;
-          const double y0 = self_is_a ? -a0 : a0, y1 = self_is_a ? -a1 : a1, y2 = self_is_a ? b2 : a2;
-          S[3 * k] = x0 * ss[0]; S[3 * k + 1] = x1 * ss[1]; S[3 * k + 2] = x2 * ss[2];
-          O[3 * k] = y0 * so[0]; O[3 * k + 1] = y1 * so[1]; O[3 * k + 2] = y2 * so[2];
-        }
-        // METHOD 2: elimination coefficients of this edge's switch (c == 0 for ordinary edges)
-        double cc = 0.0, gam = 0.0, vs[3] = {0.0, 0.0, 0.0}, vo[3] = {0.0, 0.0, 0.0};
-        if constexpr (SC) {
-          const int64_t le = ed >> 1;
-          cc = A.sw_c[le];
-          if (cc != 0.0) {
-            const double* j = A.sw_js + 3 * le;
-            gam = A.sw_gamma[le];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-              vs[a] = S[a] * j[0] + S[3 + a] * j[1] + S[6 + a] * j[2];
-              vo[a] = O[a] * j[0] + O[3 + a] * j[1] + O[6 + a] * j[2];
-            }
-          }
-        }
-        double HB[9];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) {
-            double v = S[a] * O[b] + S[3 + a] * O[3 + b] + S[6 + a] * O[6 + b];
-            if constexpr (SC) v -= cc * vs[a] * vo[b];  // J'(I - c j j')J
-            HB[3 * a + b] = v;
-          }
-        hoff_store(A.hoff, q, HB);
-        // chain preconditioner: the block (i, i-1) goes straight into the factorisation's input record (C part), so that
-        // no kernel has to dig it out of the AoSoA block stream again (k_chain_extract read 975 MB to find 72 MB).  With
-        // several edges between i-1 and i the first incidence writes and k_chain_dupfix replaces it by the ordered sum.
-        if (A.chain_rec != nullptr && col == (int64_t)A.lo + row - 1 && (row % A.chain_seg) != 0 &&
-            (q == A.inc_ptr[row] || A.inc_col[q - 1] != (int32_t)col)) {
-          double2* o = reinterpret_cast<double2*>(A.chain_rec + (int64_t)row * CHAIN_REC + 6);
-          o[0] = make_double2(HB[0], HB[1]);
-          o[1] = make_double2(HB[2], HB[3]);
-          o[2] = make_double2(HB[4], HB[5]);
-          o[3] = make_double2(HB[6], HB[7]);
-          A.chain_rec[(int64_t)row * CHAIN_REC + 14] = HB[8];
-        }
-        double d0 = S[0] * S[0] + S[3] * S[3] + S[6] * S[6], d1 = S[0] * S[1] + S[3] * S[4] + S[6] * S[7];
-        double d2 = S[0] * S[2] + S[3] * S[5] + S[6] * S[8], d3 = S[1] * S[1] + S[4] * S[4] + S[7] * S[7];
-        double d4 = S[1] * S[2] + S[4] * S[5] + S[7] * S[8], d5 = S[2] * S[2] + S[5] * S[5] + S[8] * S[8];
-        double g0 = S[0] * R[R0] + S[3] * R[R0 + 1] + S[6] * R[R0 + 2], g1 = S[1] * R[R0] + S[4] * R[R0 + 1] + S[7] * R[R0 + 2];
-        double g2 = S[2] * R[R0] + S[5] * R[R0 + 1] + S[8] * R[R0 + 2];
-        if constexpr (SC) {
-          scr[9][tid] = d0;  scr[10][tid] = d3; scr[11][tid] = d5;   // unreduced diagonal and gradient
-          scr[12][tid] = g0; scr[13][tid] = g1; scr[14][tid] = g2;
-          d0 -= cc * vs[0] * vs[0]; d1 -= cc * vs[0] * vs[1]; d2 -= cc * vs[0] * vs[2];
-          d3 -= cc * vs[1] * vs[1]; d4 -= cc * vs[1] * vs[2]; d5 -= cc * vs[2] * vs[2];
-          g0 -= gam * vs[0]; g1 -= gam * vs[1]; g2 -= gam * vs[2];  // J'(r - gamma j)
-        }
-        scr[0][tid] = d0; scr[1][tid] = d1; scr[2][tid] = d2; scr[3][tid] = d3; scr[4][tid] = d4; scr[5][tid] = d5;
-        scr[6][tid] = g0; scr[7][tid] = g1; scr[8][tid] = g2;
+  int t = xr.begin;
+  if (t >= xr.end) return;
+  int4 d = A.tile_desc[t];
+  int ed = 0, col = 0, roff = 0;
+  if (d.w <= WG && tid < d.w) {
+    ed = A.inc_edge[d.z + tid];
+    col = A.inc_col[d.z + tid];
+    roff = A.inc_rowoff[d.z + tid];
+  }
+  int buf = 0;
+  for (; t < xr.end; t += xr.step) {
+    const int r0 = d.x, nrows = d.y, q0 = d.z, nq = d.w;
+    const int tn = t + xr.step;
+    int4 dn = d;
+    if (tn < xr.end) dn = A.tile_desc[tn];
+    if (nq <= WG) {
+      if (tid <= nrows) sptr[buf][tid] = A.inc_ptr[r0 + tid] - q0;
+      int ed_n = 0, col_n = 0, roff_n = 0;
+      if (tid < nq) {
+        const int q = q0 + tid;
+        const bool first_of_pair = tid == 0 || roff != (int)A.inc_rowoff[q - 1] || A.inc_col[q - 1] != col;
+        asm_incidence<SC, INFO>(A, q, ed, (int64_t)col, r0 + roff, first_of_pair, tid, scr[buf]);
+      }
+      if (tn < xr.end && dn.w <= WG && tid < dn.w) {   // (the descriptor was this iteration's first load)
+        ed_n = A.inc_edge[dn.z + tid];
+        col_n = A.inc_col[dn.z + tid];
+        roff_n = A.inc_rowoff[dn.z + tid];
       }
       __syncthreads();
       for (int idx = tid; idx < nrows * NS; idx += WG) {
         const int c = idx / nrows, rl = idx - c * nrows;
-        const int row = r0 + rl;
-        int lo = A.inc_ptr[row], hi = A.inc_ptr[row + 1];
-        lo = max(lo, base) - base;
-        hi = min(hi, base + WG) - base;
+        const int lo = sptr[buf][rl], hi = sptr[buf][rl + 1];
         double s = 0.0;
-        for (int j = lo; j < hi; ++j) s += scr[c][j];
-        if (multi) {
-          acc += s;  // nrows == 1: idx == tid == c
-        } else if (c < 6) {
-          A.hd[(int64_t)c * A.n_loc + row] = s;
-        } else if (c < 9) {
-          A.gs[3 * (int64_t)row + (c - 6)] = s;
-        } else if (c < 12) {
-          A.diag_full[3 * (int64_t)row + (c - 9)] = s;
-        } else {
-          A.gs_full[3 * (int64_t)row + (c - 12)] = s;
-        }
+        for (int j = lo; j < hi; ++j) s += scr[buf][c][j];
+        asm_store_row<SC>(A, c, r0 + rl, s);
       }
-      __syncthreads();
-      if (q1 == q0) break;
+      buf ^= 1;
+      ed = ed_n; col = col_n; roff = roff_n;
+    } else {
+      // ---- one heavy row (> 256 incidences): chunks of 256, two barriers per chunk, the sums carried in registers
+      const int q1 = q0 + nq;
+      double acc = 0.0;  // tid < NS
+      for (int base = q0; base < q1; base += WG) {
+        const int q = base + tid;
+        if (q < q1) {
+          const int e2 = A.inc_edge[q];
+          const int c2 = A.inc_col[q];
+          const bool first_of_pair = q == q0 || A.inc_col[q - 1] != c2;
+          asm_incidence<SC, INFO>(A, q, e2, (int64_t)c2, r0, first_of_pair, tid, scr[buf]);
+        }
+        __syncthreads();
+        if (tid < NS) {
+          const int hi = min(q1, base + WG) - base;
+          double s = 0.0;
+          for (int j = 0; j < hi; ++j) s += scr[buf][tid][j];
+          acc += s;
+        }
+        __syncthreads();
+      }
+      if (tid < NS) asm_store_row<SC>(A, tid, r0, acc);
+      if (tn < xr.end && dn.w <= WG && tid < dn.w) {
+        ed = A.inc_edge[dn.z + tid];
+        col = A.inc_col[dn.z + tid];
+        roff = A.inc_rowoff[dn.z + tid];
+      }
     }
-    if (multi && tid < NS) {
-      if (tid < 6) A.hd[(int64_t)tid * A.n_loc + r0] = acc;
-      else if (tid < 9) A.gs[3 * (int64_t)r0 + (tid - 6)] = acc;
-      else if (tid < 12) A.diag_full[3 * (int64_t)r0 + (tid - 9)] = acc;
-      else A.gs_full[3 * (int64_t)r0 + (tid - 12)] = acc;
-    }
+    d = dn;
   }
 }
 

@@ -56,6 +56,7 @@ struct ShardStructure {
   std::vector<int32_t> inc_ptr;         // n_loc + 1
   std::vector<int32_t> inc_edge;        // (local edge << 1) | side
   std::vector<int32_t> inc_col;         // global pose position of the other endpoint
+  std::vector<uint8_t> inc_rowoff;      // row of the incidence - first row of its tile (< TILE_INC)
 
   // tiles: contiguous row ranges with <= TILE_INC incidences (a row with more
   // incidences forms a tile of its own and is processed in chunks)

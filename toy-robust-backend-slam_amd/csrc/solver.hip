@@ -108,6 +108,7 @@ struct pgo_handle {
   double* chi2_buf = nullptr;  // [n_edges_total], allocated at the first pgo_edge_chi2
   int64_t n_edges_total = 0;
   int32_t *inc_ptr = nullptr, *inc_edge = nullptr, *inc_col = nullptr, *tile_row = nullptr;
+  uint8_t* inc_rowoff = nullptr;
   int4* tile_desc = nullptr;
   bool spmv_pipe = false;   // software-pipelined K3 (k_spmv_p): when no tile is a chunked heavy row or has > 85 rows
   int64_t inc_stride = 0;
@@ -122,7 +123,10 @@ struct pgo_handle {
   int32_t *co_cb_i = nullptr, *co_cb_j = nullptr, *co_cb_ptr = nullptr, *co_cb_q = nullptr, *co_cb_row = nullptr;
   int coarse_setup();      // create: aggregates, coarse block lists, buffers
   int coarse_factor();     // per LM iteration: basis, Galerkin matrix, Cholesky + inverse factor
-  int coarse_apply(double* p_or_null, double* extra_rz, const int32_t* done);   // z += P (P'(H + D'D)P)^-1 P' r
+  double* co_ainv = nullptr;   // explicit inverse N'N (coarse orders <= COARSE_EXPLICIT_RANK: one product per apply)
+  int32_t* co_ok = nullptr;    // device flag: the factorisation of this LM iteration is usable
+  int co_ndot = 0;             // partials of r_c . e_c appended to the r.z partials
+  int coarse_solve(double* dot_part, const int32_t* done);   // e_c = (P'(H + D'D)P)^-1 P' r  (+ partials of r_c . e_c)
   // single-reduction PCG loop (k_cg_sr_*: one all-reduce per iteration; several ranks, inexact mode, chain preconditioner)
   bool use_sr = false;
   double* sr_s = nullptr;   // s = A p, carried by recurrence
@@ -404,6 +408,8 @@ struct pgo_handle {
     A.inc_edge = inc_edge;
     A.inc_col = inc_col;
     A.tile_row = tile_row;
+    A.inc_rowoff = inc_rowoff;
+    A.tile_desc = tile_desc;
     A.scale = scale;
     A.n_tiles = S.n_tiles();
     A.n_loc = S.n_loc;
@@ -703,6 +709,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(dalloc(&inc_edge, S.n_inc));
   PGOC(dalloc(&inc_col, S.n_inc));
   PGOC(dalloc(&tile_row, (int64_t)S.tile_row.size()));
+  PGOC(dalloc(&inc_rowoff, std::max<int64_t>(S.n_inc, 1)));
   PGOC(dalloc(&hoff, 9 * inc_stride));
   PGOC(dalloc(&hd, 6 * NL));
   PGOC(dalloc(&gs, 3 * NL));
@@ -734,8 +741,8 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   g_flat = std::min(std::max(1, cdiv(3 * NL, dev::WG)), 1024);
   if (const char* fe = PGO_EXP_ENV("PGO_FLAT_GRID")) g_flat = std::min(g_flat, std::max(8, atoi(fe)));
   g_spmv = up8(std::min(std::max(1, S.n_tiles()), 2048));
-  g_asm = up8(std::min(std::max(1, S.n_tiles()), 1 << 20));
-  part_cap = std::max(g_edge, 2048) + 8;
+  g_asm = up8(std::min(std::max(1, S.n_tiles()), 256 * 6));   // persistent workgroups: the pipelined K2 walks ~20 tiles each at 1M poses
+  part_cap = std::max(g_edge, 2048) + 8 + 512;   // (+ the coarse level's dot partials behind the one-level r.z partials)
   for (int k = 0; k < N_PART; ++k) PGOC(dalloc(&part[k], part_cap));
 
   HIPC(hipMemcpyAsync(poses, poses_h, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -757,6 +764,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   PGOC(upload(inc_edge, S.inc_edge));
   PGOC(upload(inc_col, S.inc_col));
   PGOC(upload(tile_row, S.tile_row));
+  PGOC(upload(inc_rowoff, S.inc_rowoff));
   {  // one 16-byte descriptor per tile for K3: {first local row, rows, first incidence, incidences}
     // in breadth-first order of the tile graph (compute_tile_order): tiles running together gather the same lines
     std::vector<int4> desc((size_t)std::max(1, S.n_tiles()));
@@ -974,13 +982,13 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
 // Second preconditioner level (coarse.hip.h).  opt.pcg_coarse_poses: 0 = off, > 0 = poses per aggregate, -1 = auto.
 namespace {
 constexpr int COARSE_MAX_RANK = 6144;   // order of the dense coarse matrix (k_chol_panel's range)
+constexpr int COARSE_EXPLICIT_RANK = 1024;   // up to here the explicit inverse N'N is formed once per LM iteration
 }
 int pgo_handle::coarse_setup() {
   const int world = comm ? comm->world : 1;
   const int64_t NL = S.n_loc;
   int want = opt.pcg_coarse_poses;
   if (want == 0) return PGO_OK;
-  const int unit = chain_len ? chain_len : grp_B;   // aggregates are unions of the one-level blocks
   auto no = [&](const std::string& why) -> int {
     if (want > 0) return fail(PGO_ERR_UNSUPPORTED, "pcg_coarse_poses: " + why);
     return PGO_OK;
@@ -996,7 +1004,6 @@ int pgo_handle::coarse_setup() {
     want = 16;
     while (3 * ((NL + want - 1) / want) > 2400) want *= 2;
   }
-  if (want % unit != 0) want = ((want + unit - 1) / unit) * unit;
   co_agg = want;
   co_nagg = (int)((NL + co_agg - 1) / co_agg);
   co_K = 3 * co_nagg;
@@ -1052,6 +1059,11 @@ int pgo_handle::coarse_setup() {
   PGOC(dalloc(&co_rc, co_Kp));
   PGOC(dalloc(&co_cy, co_Kp));
   PGOC(dalloc(&co_ec, co_Kp));
+  PGOC(dalloc(&co_ok, 1));
+  if (co_Kp <= COARSE_EXPLICIT_RANK) PGOC(dalloc(&co_ainv, (int64_t)co_Kp * co_Kp));
+  co_ndot = co_ainv ? (co_Kp + 3) / 4 : (co_Kp + 255) / 256;
+  if (g_chain + co_ndot + 8 > part_cap || g_grp + co_ndot + 8 > part_cap || g_vec + co_ndot + 8 > part_cap)
+    return no("internal: not enough room for the coarse level's dot partials");
   PGOC(dalloc(&co_cb_i, co_ncb));
   PGOC(dalloc(&co_cb_j, co_ncb));
   PGOC(dalloc(&co_cb_ptr, co_ncb + 1));
@@ -1110,19 +1122,33 @@ int pgo_handle::coarse_factor() {
     hipLaunchKernelGGL(dev::k_chol_panel, dim3(std::max(1, nb - 1)), dim3(dev::CHOL_THREADS), dev::CHOL_LDS_BYTES, stream, co_cap, co_nm, co_dwork, co_Kp, nb, kb);
     PGOC(check_launch("k_chol_panel (coarse level)"));
   }
-  return PGO_OK;
+  // usable?  a probe through the factor: x = A_c^-1 1 must be finite (a pivot lost to rounding leaves NaNs behind it)
+  hipLaunchKernelGGL(dev::k_fill, dim3((co_Kp + 255) / 256), dim3(256), 0, stream, co_rc, (int64_t)co_Kp, 1.0);
+  if (co_ainv) {
+    hipLaunchKernelGGL(dev::k_coarse_ainv, dim3((co_Kp + 255) / 256, co_Kp), dim3(256), 0, stream, (const double*)co_nm, co_Kp, co_ainv);
+    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_ainv, co_Kp, nb, (const double*)co_rc, co_ec, 0);
+  } else {
+    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_rc, co_cy, 0);
+    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_cy, co_ec, 1);
+  }
+  hipLaunchKernelGGL(dev::k_coarse_check, dim3(1), dim3(256), 0, stream, (const double*)co_ec, co_Kp, co_ok);
+  return check_launch("coarse level probe");
 }
 
-int pgo_handle::coarse_apply(double* p_or_null, double* extra_rz, const int32_t* done) {
+int pgo_handle::coarse_solve(double* dot_part, const int32_t* done) {
   const int nb = co_Kp / 32;
   hipLaunchKernelGGL(dev::k_coarse_restrict, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, (int)S.n_loc, co_agg, co_nagg, (const double*)co_pb,
                      (const double*)r, co_rc, done);
-  hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_rc, co_cy, 0);
-  hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_cy, co_ec, 1);
-  const int g = (int)std::min<int64_t>((S.n_loc + 255) / 256, 512);
-  hipLaunchKernelGGL(dev::k_coarse_prolong, dim3(g), dim3(256), 0, stream, (int)S.n_loc, co_agg, co_K, (const double*)co_pb, (const double*)co_rc,
-                     (const double*)co_ec, z, p_or_null, extra_rz, done);
-  return check_launch("coarse level apply");
+  if (co_ainv) {
+    hipLaunchKernelGGL(dev::k_coarse_matvec, dim3(co_ndot), dim3(256), 0, stream, (const double*)co_ainv, co_Kp, (const double*)co_rc, co_ec,
+                       dot_part, (const int32_t*)co_ok, done);
+  } else {
+    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_rc, co_cy, 0);
+    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_cy, co_ec, 1);
+    hipLaunchKernelGGL(dev::k_coarse_dot, dim3(co_ndot), dim3(256), 0, stream, co_Kp, (const double*)co_rc, co_ec, dot_part,
+                       (const int32_t*)co_ok, done);
+  }
+  return check_launch("coarse level solve");
 }
 
 // evaluate (K1, unscaled records) + assemble (K2, applies the current `scale`) at `poses`;
@@ -1642,8 +1668,13 @@ int pgo_handle::pcg(int* iters, double* rel) {
     PGOC(sr_product_and_scalars(1));
   } else {
     // two levels: z (= p) of the start-up kernel gets the coarse correction, r.z one more partial
-    const int n_rz0 = use_coarse ? g_u1 + 1 : g_u1;
-    if (use_coarse) PGOC(coarse_apply(p_full + dev::PS * (int64_t)S.lo, part[0] + g_u1, nullptr));
+    const int n_rz0 = use_coarse ? g_u1 + co_ndot : g_u1;
+    if (use_coarse) {
+      PGOC(coarse_solve(part[0] + g_u1, nullptr));
+      hipLaunchKernelGGL(dev::k_coarse_prolong, dim3((unsigned)std::min<int64_t>((S.n_loc + 255) / 256, 512)), dim3(256), 0, stream, (int)S.n_loc,
+                         co_agg, (const double*)co_pb, (const double*)co_ec, z, p_full + dev::PS * (int64_t)S.lo, (const int32_t*)co_ok);
+      PGOC(check_launch("k_coarse_prolong"));
+    }
     PGOC(reduce_to_scal({{part[0], n_rz0, 0}, {part[1], g_u1, 0}}, 4));
     hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
     PGOC(check_launch("k_cg_init_fin"));
@@ -1687,10 +1718,11 @@ int pgo_handle::pcg(int* iters, double* rel) {
     else hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, par, pap, n_pap, part[1], part[2]);
     PGOC(check_launch("k_cg_update1"));
     if (fused) return PGO_OK;  // its r.z / r.r partials are booked by the next SpMV, or by k_cg_book at the end of the slice
-    if (use_coarse) {   // second level: z += P e_c, its share of r.z as one more partial (single rank)
-      PGOC(coarse_apply(nullptr, part[1] + g_u1, &st->done));
-      hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_u1 + 1, part[2], g_u1);
-      return check_launch("k_cg_update2");
+    if (use_coarse) {   // second level (single rank): e_c, its share of r.z as more partials, prolongation inside the direction update
+      PGOC(coarse_solve(part[1] + g_u1, &st->done));
+      hipLaunchKernelGGL(dev::k_cg_update2c, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, (const double*)part[1], g_u1 + co_ndot,
+                         (const double*)part[2], g_u1, co_agg, (const double*)co_pb, (const double*)co_ec);
+      return check_launch("k_cg_update2c");
     }
     if (multi) {
       PGOC(reduce_to_scal({{part[1], g_u1, 0}, {part[2], g_u1, 0}}, 7));
@@ -1907,11 +1939,17 @@ int pgo_handle::prepare_preconditioner() {
 // block LDL' of the chain preconditioner's segments (the records are complete: C part from k_assemble, M part from k_prepare)
 int pgo_handle::factor_chain() {
   const int n_seg = (S.n_loc + chain_len - 1) / chain_len;
+  // One THREAD per segment runs the recurrence (64 .. 256 dependent steps), so the kernel lives on memory requests in
+  // flight, not on lanes: with 64 segments per wavefront the 15.6k segments of the 1M-pose graph are 244 wavefronts --
+  // one per compute unit, 32 KB in flight each, 0.25 of the HBM roofline.  16 segments per wavefront (4 wavefronts per
+  // compute unit, each with its own queue of outstanding loads) quadruple that.
+  int spw = 64;
+  while (spw > 8 && n_seg / spw < 1024) spw >>= 1;
   if ((chain_chunk ? chain_chunk : dev::CHAIN_CHUNK) == 2)
-    hipLaunchKernelGGL(dev::k_chain_factor<2>, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
+    hipLaunchKernelGGL(dev::k_chain_factor<2>, dim3((n_seg + spw - 1) / spw), dim3(spw), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
                        chain_len, chain_w, chain_s);
   else
-    hipLaunchKernelGGL(dev::k_chain_factor<4>, dim3((n_seg + 63) / 64), dim3(64), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
+    hipLaunchKernelGGL(dev::k_chain_factor<4>, dim3((n_seg + spw - 1) / spw), dim3(spw), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
                        chain_len, chain_w, chain_s);
   return check_launch("k_chain_factor");
 }
@@ -2992,7 +3030,12 @@ int pgo_debug_precond(pgo_t* h, const double* r_in, double* z_out) {
     hipLaunchKernelGGL(dev::k_cg_init, dim3(h->g_vec), dim3(dev::WG), 0, h->stream, V, (const double*)h->ap, h->part[0], h->part[1]);
   }
   PGOC(h->check_launch("k_cg_init (debug)"));
-  if (h->use_coarse) PGOC(h->coarse_apply(nullptr, h->part[0] + 2048, nullptr));   // the second level's share of z
+  if (h->use_coarse) {   // the second level's share of z
+    PGOC(h->coarse_solve(h->part[3], nullptr));
+    hipLaunchKernelGGL(dev::k_coarse_prolong, dim3((unsigned)std::min<int64_t>((h->S.n_loc + 255) / 256, 512)), dim3(256), 0, h->stream,
+                       (int)h->S.n_loc, h->co_agg, (const double*)h->co_pb, (const double*)h->co_ec, h->z, (double*)nullptr, (const int32_t*)h->co_ok);
+    PGOC(h->check_launch("k_coarse_prolong"));
+  }
   std::vector<double> ztmp((size_t)3 * N);
   HIPC(hipMemcpyAsync(ztmp.data(), h->z, ztmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PGOC(h->sync());

@@ -351,6 +351,12 @@ int build_shard_structure(int32_t N, int32_t E, const int32_t* ia, const int32_t
     S->tile_row.push_back(row);
   }
   if (S->n_loc == 0) S->tile_row.assign(1, 0);
+  // row of every incidence relative to its tile's first row (a tile has at most TILE_INC rows): K2's lanes read it
+  // instead of searching inc_ptr
+  S->inc_rowoff.assign((size_t)S->n_inc, 0);
+  for (int32_t t = 0; t + 1 < (int32_t)S->tile_row.size(); ++t)
+    for (int32_t r = S->tile_row[t]; r < S->tile_row[t + 1]; ++r)
+      for (int32_t q = ptr[r]; q < ptr[r + 1]; ++q) S->inc_rowoff[q] = (uint8_t)(r - S->tile_row[t]);
   return PGO_OK;
 }
 
