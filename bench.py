@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def kernels_digest():
     """identifies the kernel sources a committed PMC traffic figure belongs to"""
     h = hashlib.sha256()
-    for f in ("kernels.hip.h", "solver.hip"):
+    for f in ("kernels.hip.h", "coarse.hip.h", "solver_handle.hip.h", "solver_launch.hip", "solver_pcg.hip", "solver_lm.hip", "solver_create.hip"):
         h.update(open(os.path.join(ROOT, "toy-robust-backend-slam_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -112,7 +112,7 @@ def main():
     wf = cal.get("write_factor_k_scatter", 1.0)
     import hashlib
     hh = hashlib.sha256()
-    for f in ("kernels.hip.h", "solver.hip"):
+    for f in ("kernels.hip.h", "coarse.hip.h", "solver_handle.hip.h", "solver_launch.hip", "solver_pcg.hip", "solver_lm.hip", "solver_create.hip"):
         hh.update(open(os.path.join(root, "toy-robust-backend-slam_amd", "csrc", f), "rb").read())
     traffic = {"kernels_digest": hh.hexdigest()[:16], "profile_tag": tag, "calibration": cal, "read_factor_used": rf, "write_factor_used": wf,
                "note": "bytes per launch = FETCH_SIZE*1024*read_factor + WRITE_SIZE*1024*write_factor (gfx950: FETCH_SIZE "

@@ -297,8 +297,9 @@ def test_auto_changes_to_the_direct_solve_when_pcg_is_expensive(pgo):
     iteration) and FRH end on the direct solve, M3500 without DCS (< 100 after the first ten) returns to PCG"""
     for name, method, ends_direct in (("M3500", 1, True), ("M3500", 0, False), ("FRH", 1, True)):
         runs = []
-        s = pgo.Solver(load(pgo, name), pgo.Options(method=method, pcg_max_iters=400000))
-        assert s.info().linear_solver == 1
+        # (one preconditioner level: with the default second level these graphs stay on PCG, see test_two_level_preconditioner)
+        s = pgo.Solver(load(pgo, name), pgo.Options(method=method, pcg_max_iters=400000, pcg_coarse_poses=0))
+        assert s.info().linear_solver == 1 and s.info().pcg_coarse_poses == 0
         for _ in range(2):   # the second solve of the handle takes the same decisions: identical result
             s.set_poses(np.array(load(pgo, name).poses))
             sm = s.solve()
@@ -312,16 +313,84 @@ def test_auto_changes_to_the_direct_solve_when_pcg_is_expensive(pgo):
         s.close()
 
 
+@pytest.mark.parametrize("name,method", [("M3500", 1), ("M3500", 0), ("FRH", 1)])
+def test_two_level_preconditioner(pgo, name, method):
+    """the second preconditioner level (csrc/coarse.hip.h: additive coarse correction on the rigid-body modes of pose
+    aggregates) is the library's default for exact-mode PCG solves of graphs the direct solve does not take cheaply:
+    same LM history and poses as the one-level solve and as the golden direct-solve fixture, several times fewer PCG
+    iterations, bitwise reproducible (the Galerkin matrix is summed in a fixed order)"""
+    g = load(pgo, name)
+    tag = "%s_out0_m%d" % (name, method)
+    fx = json.load(open(os.path.join(GOLDEN, "lm_%s.json" % tag)))
+    ref = np.load(os.path.join(GOLDEN, "lm_%s_poses.npy" % tag))
+    one = pgo.Solver(g, pgo.Options(method=method, linear_solver=1, pcg_coarse_poses=0, pcg_max_iters=400000))
+    s1 = one.solve()
+    runs = []
+    two = pgo.Solver(g, pgo.Options(method=method, pcg_max_iters=400000))
+    i = two.info()
+    assert i.linear_solver == 1 and i.pcg_coarse_poses > 0 and 0 < i.pcg_coarse_rank <= 2400
+    for _ in range(2):
+        two.set_poses(np.array(g.poses))
+        runs.append((two.solve(), two.poses(), two.iter_records()))
+    s2, x2, recs = runs[1]
+    print("%s METHOD %d: PCG iterations one level %d, two levels %d (aggregates of %d poses, coarse order %d); %.0f vs %.0f GN it/s"
+          % (name, method, s1.total_pcg_iters, s2.total_pcg_iters, i.pcg_coarse_poses, i.pcg_coarse_rank,
+             s1.iterations / s1.seconds_total, s2.iterations / s2.seconds_total))
+    assert two.info().direct_switched_at == 0
+    assert [r["step_ok"] for r in recs] == [r["step_ok"] for r in fx["records"]] == [r["step_ok"] for r in one.iter_records()]
+    assert s2.final_cost == pytest.approx(fx["final_cost"], rel=1e-7)
+    assert np.abs(x2[:, :2] - ref[:, :2]).max() < 5e-6 and np.abs(x2 - one.poses()).max() < 5e-6
+    assert all(r["iter"] == 0 or r["pcg_rel_residual"] <= 1e-10 for r in recs)
+    assert 2 * s2.total_pcg_iters < s1.total_pcg_iters
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    assert runs[0][0].total_pcg_iters == runs[1][0].total_pcg_iters
+    # the operator CG sees: symmetric, positive, linear (through the apply kernels themselves)
+    rng = np.random.default_rng(3)
+    n = 3 * g.n_poses
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+    Mu, Mv = two.precond(u), two.precond(v)
+    M1u = one.precond(u)
+    assert float(u @ Mv) == pytest.approx(float(v @ Mu), rel=1e-9) and float(u @ Mu) > float(u @ M1u) > 0.0
+    np.testing.assert_allclose(two.precond(2.0 * u - 3.0 * v), 2.0 * Mu - 3.0 * Mv, rtol=1e-8, atol=1e-9 * np.abs(Mu).max())
+    one.close(); two.close()
+
+
+def test_two_level_preconditioner_on_synthetic_graphs(pgo, oracle):
+    """the same on a synthetic graph with the chain preconditioner as the first level (30011 poses, aggregates chosen by
+    the library), tight and loose tolerances: identical accept / reject history, fewer PCG iterations; an explicit
+    aggregate size is honoured; several ranks or a batched handle refuse an explicit request and ignore the auto one"""
+    g = pgo.synth_manhattan(30011, 4.0, 0.10, 5)
+    kw = dict(method=1, max_iters=6, ftol=0.0, gtol=0.0, ptol=0.0, pcg_max_iters=200000, pcg_chain_len=64)
+    out = {}
+    for rtol in (1e-8, 1e-3):
+        for coarse in (0, -1, 128):
+            s = pgo.Solver(g, pgo.Options(pcg_rtol=rtol, pcg_coarse_poses=coarse, **kw))
+            sm = s.solve()
+            out[(rtol, coarse)] = (sm, s.poses(), [r["step_ok"] for r in s.iter_records()], s.info().pcg_coarse_poses)
+            s.close()
+        assert out[(rtol, 128)][3] == 128 and out[(rtol, 0)][3] == 0
+        assert (out[(rtol, -1)][3] > 0) == (rtol <= 1e-4)      # auto: the exact mode only
+        for coarse in (-1, 128):
+            assert out[(rtol, coarse)][2] == out[(rtol, 0)][2]
+            assert out[(rtol, coarse)][0].final_cost == pytest.approx(out[(rtol, 0)][0].final_cost, rel=1e-6 if rtol < 1e-6 else 1e-3)
+        assert out[(rtol, 128)][0].total_pcg_iters < 0.6 * out[(rtol, 0)][0].total_pcg_iters
+        print("30011 poses, rtol %g: PCG iterations one level %d, auto %d (aggregates %d), aggregates of 128: %d" % (
+            rtol, out[(rtol, 0)][0].total_pcg_iters, out[(rtol, -1)][0].total_pcg_iters, out[(rtol, -1)][3], out[(rtol, 128)][0].total_pcg_iters))
+    assert np.abs(out[(1e-8, 128)][1] - out[(1e-8, 0)][1]).max() < 1e-6
+    with pytest.raises(pgo.PgoError):
+        pgo.Solver(g, pgo.Options(pcg_rtol=1e-8, pcg_coarse_poses=1, **kw))     # coarse order 90033 > 6143
+
+
 def test_direct_setup_failure_keeps_the_solve_on_pcg(pgo):
     """auto mode above rank 2048 sets the direct solver up in the MIDDLE of a solve (about 1 GB of buffers at rank 5862): if
     that fails (here through the test hook, as a hipMalloc failure would) the solve goes on with PCG -- a heuristic speed-up
     never becomes a failed pgo_solve -- the partial buffers are freed and the handle does not try again"""
     g = load(pgo, "M3500")
-    ref = pgo.Solver(g, pgo.Options(method=1, linear_solver=1, pcg_max_iters=400000, max_iters=8))
+    ref = pgo.Solver(g, pgo.Options(method=1, linear_solver=1, pcg_max_iters=400000, max_iters=8, pcg_coarse_poses=0))
     sr = ref.solve()
     pgo.set_knob("direct_setup_fail", 1)
     try:
-        s = pgo.Solver(g, pgo.Options(method=1, pcg_max_iters=400000, max_iters=8))
+        s = pgo.Solver(g, pgo.Options(method=1, pcg_max_iters=400000, max_iters=8, pcg_coarse_poses=0))
         bytes0 = s.info().device_bytes
         sm = s.solve()
     finally:

@@ -10,8 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libpgo.so")
-SOURCES = ["host_graph.cpp", "structure.cpp", "comm.cpp", "solver.hip"]
-HEADERS = ["pgo_internal.h", "comm.h", "kernels.hip.h", "solo.hip.h", "direct.hip.h", os.path.join(ROOT, "include", "pgo.h")]
+SOURCES = ["host_graph.cpp", "structure.cpp", "comm.cpp", "solver_create.hip", "solver_lm.hip", "solver_pcg.hip", "solver_direct.hip",
+           "solver_batch.hip", "solver_abi.hip", "solver_launch.hip"]
+HEADERS = ["pgo_internal.h", "comm.h", "kernels.hip.h", "solo.hip.h", "direct.hip.h", "coarse.hip.h", "solver_handle.hip.h",
+           os.path.join(ROOT, "include", "pgo.h")]
 
 
 def _hipcc() -> str:
@@ -33,13 +35,25 @@ def build_lib(force: bool = False, verbose: bool = False, defines=(), out: str =
     """`defines` / `out`: experiment builds (scripts/exp_*.sh) next to the product library, selected with PGO_LIB"""
     if not force and not needs_build() and out == LIB:
         return LIB
-    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", out + ".tmp", "-lrccl", "-pthread"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # one object per translation unit, compiled side by side (the device code of a unit = the kernels it launches), then linked
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-function",
+             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines]
+    with tempfile.TemporaryDirectory(prefix="pgo_build_") as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+            cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out + ".tmp", "-lrccl", "-pthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     os.replace(out + ".tmp", out)
     return out
 

@@ -80,7 +80,7 @@ __device__ __forceinline__ double wave_sum_fixed(double v) {
 }
 
 // one wavefront per aggregate: centre of the aggregate's poses, then the basis planes of its poses
-__global__ __launch_bounds__(256) void k_coarse_basis(CoarseArgs A) {
+static __global__ __launch_bounds__(256) void k_coarse_basis(CoarseArgs A) {
   const int w = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (w >= A.n_agg) return;
   const int i0 = w * A.agg, i1 = min(A.n_loc, i0 + A.agg);
@@ -125,7 +125,7 @@ __device__ __forceinline__ void coarse_accumulate(double (&C)[9], const PBasis& 
 // partial 3x3 sums are added in a fixed tree -- the same bits on every run.  Block (I, I) also takes the diagonal blocks
 // H_ii + D'D of its poses.  Writes the block into the dense matrix and, for blocks on the block diagonal of the 32 x 32
 // partition, into `dwork`.
-__global__ __launch_bounds__(256) void k_coarse_assemble(CoarseArgs A) {
+static __global__ __launch_bounds__(256) void k_coarse_assemble(CoarseArgs A) {
   const int b = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (b >= A.n_cb) return;
   const int I = A.cb_i[b], J = A.cb_j[b];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_coarse_assemble(CoarseArgs A) {
 }
 
 // identity on the padding rows K .. Kp-1 of the (zeroed) coarse matrix and of dwork
-__global__ void k_coarse_pad(double* __restrict__ cap, double* __restrict__ dwork, int K, int Kp) {
+static __global__ void k_coarse_pad(double* __restrict__ cap, double* __restrict__ dwork, int K, int Kp) {
   const int p = K + blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= Kp) return;
   cap[(int64_t)p * Kp + p] = 1.0;
@@ -171,7 +171,7 @@ __global__ void k_coarse_pad(double* __restrict__ cap, double* __restrict__ dwor
 }
 
 // r_c = P' r: one wavefront per aggregate, fixed order
-__global__ __launch_bounds__(256) void k_coarse_restrict(int n_loc, int agg, int n_agg, const double* __restrict__ pb,
+static __global__ __launch_bounds__(256) void k_coarse_restrict(int n_loc, int agg, int n_agg, const double* __restrict__ pb,
                                                          const double* __restrict__ r, double* __restrict__ rc,
                                                          const int32_t* __restrict__ done) {
   if (done && *done) return;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_coarse_restrict(int n_loc, int agg, int
 }
 
 // z += P e_c and the same into the gather vector p (the PCG start-up, where p = z); skipped as a whole when the level is off
-__global__ __launch_bounds__(256) void k_coarse_prolong(int n_loc, int agg, const double* __restrict__ pb, const double* __restrict__ ec,
+static __global__ __launch_bounds__(256) void k_coarse_prolong(int n_loc, int agg, const double* __restrict__ pb, const double* __restrict__ ec,
                                                         double* __restrict__ z, double* __restrict__ p, const int32_t* __restrict__ ok) {
   if (!*ok) return;
   const int64_t n = n_loc;
@@ -220,13 +220,13 @@ __global__ __launch_bounds__(256) void k_coarse_prolong(int n_loc, int agg, cons
   }
 }
 
-__global__ void k_fill(double* __restrict__ x, int64_t n, double v) {
+static __global__ void k_fill(double* __restrict__ x, int64_t n, double v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = v;
 }
 
 // explicit inverse of the coarse matrix, Ainv = N'N (N = L^-1, lower triangular), for small orders: one thread per entry
-__global__ __launch_bounds__(256) void k_coarse_ainv(const double* __restrict__ Nm, int Kp, double* __restrict__ Ainv) {
+static __global__ __launch_bounds__(256) void k_coarse_ainv(const double* __restrict__ Nm, int Kp, double* __restrict__ Ainv) {
   const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
   if (j >= Kp) return;
   double s = 0.0;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_coarse_ainv(const double* __restrict__ 
 
 // the level is usable iff a probe of the factor is finite: x = Ainv 1 (explicit inverse) or x = N'(N 1) computed by the
 // caller with k_tri_apply; one workgroup
-__global__ __launch_bounds__(256) void k_coarse_check(const double* __restrict__ x, int K, int32_t* __restrict__ ok) {
+static __global__ __launch_bounds__(256) void k_coarse_check(const double* __restrict__ x, int K, int32_t* __restrict__ ok) {
   __shared__ int bad;
   if (threadIdx.x == 0) bad = 0;
   __syncthreads();
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_coarse_check(const double* __restrict__
 
 // e_c = Ainv r_c (dense, symmetric, order Kp <= 1024): one wavefront per row, four rows per workgroup; the workgroup's
 // share of r_c . e_c goes to dot_part[blockIdx.x] (fixed order).  Level off: e_c = 0, partials 0.
-__global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict__ Ainv, int Kp, const double* __restrict__ rc,
+static __global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict__ Ainv, int Kp, const double* __restrict__ rc,
                                                        double* __restrict__ ec, double* __restrict__ dot_part,
                                                        const int32_t* __restrict__ ok, const int32_t* __restrict__ done) {
   __shared__ double sh[4];
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict_
 }
 
 // large orders, after the two triangular products: partials of r_c . e_c, 256 entries per workgroup; level off: e_c = 0
-__global__ __launch_bounds__(256) void k_coarse_dot(int Kp, const double* __restrict__ rc, double* __restrict__ ec,
+static __global__ __launch_bounds__(256) void k_coarse_dot(int Kp, const double* __restrict__ rc, double* __restrict__ ec,
                                                     double* __restrict__ dot_part, const int32_t* __restrict__ ok,
                                                     const int32_t* __restrict__ done) {
   __shared__ double red[8];
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_coarse_dot(int Kp, const double* __rest
 
 // k_cg_update2 with the prolongation folded in: beta = rz_new / rz ; p = (z + P e_c) + beta p, where rz_new sums the
 // one-level partials AND the coarse level's partials of r_c . e_c (n_rz covers both).  Workgroup 0 publishes the scalars.
-__global__ __launch_bounds__(WG) void k_cg_update2c(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
+static __global__ __launch_bounds__(WG) void k_cg_update2c(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
                                                     const double* __restrict__ part_rr, int n_rr, int agg,
                                                     const double* __restrict__ pb, const double* __restrict__ ec) {
   __shared__ double red[8];

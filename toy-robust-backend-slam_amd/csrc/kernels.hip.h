@@ -237,7 +237,7 @@ __device__ __forceinline__ Chol3 chol3(double w00, double w01, double w02, doubl
 // One lane per edge.  Algorithmic bytes per edge: 8 (ia,ib) + 24 (meas) + 1 (flags) +
 // 48 (two poses) read, 112 written with the Jacobian, 0 without (INFO: + 48 read, 128 written).
 template <bool WITH_JAC, bool INFO>
-__global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict__ jr,
+static __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict__ jr,
                                                   double* __restrict__ cost_part, int* __restrict__ bad) {
   constexpr int RN = RecLayout<INFO>::N, RL = RecLayout<INFO>::LDS;
   __shared__ double stage[WITH_JAC ? WG * RL : 1];
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict
 // compute_edge_mahalanobis (src/layer_manager.cpp:230-282) for every local edge that this rank counts (flags bit1):
 // m = r' Omega r of the PLAIN residual r = (ex, ey, asin(clamp(sin delta))), clamped at 0, written to the caller's edge
 // index.  Any symmetric Omega (no factorisation).  57 B read + 48 B information + 8 B written per edge.
-__global__ __launch_bounds__(WG) void k_edge_chi2(EdgeArgs A, const int32_t* __restrict__ orig_edge, double* __restrict__ out) {
+static __global__ __launch_bounds__(WG) void k_edge_chi2(EdgeArgs A, const int32_t* __restrict__ orig_edge, double* __restrict__ out) {
   const int64_t ne = A.n_edges;
   for (int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x; e < ne; e += (int64_t)gridDim.x * WG) {
     if (!(A.flags[e] & 2u)) continue;
@@ -602,7 +602,7 @@ __device__ __forceinline__ void asm_store_row(const AsmArgs& A, int c, int row, 
 // a tile cost four dependent round trips (tile_row -> inc_ptr -> inc_edge -> record, plus an 8-step search for the row)
 // and two barriers: 433 us at 1M poses for 1.83 GB of traffic.
 template <bool SC, bool INFO>
-__global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
+static __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
   static_assert(!(SC && INFO), "switchable constraints have no information-weighted form here");
   constexpr int NS = SC ? 15 : 9;  // staged values per incidence
   __shared__ double scr[2][NS][WG];
@@ -733,7 +733,7 @@ struct SpmvArgs {
 // MODE 4 = the part of the product that needs OWNED columns only (blocks whose column lies on another rank contribute
 // 0 and are not loaded): it runs while the halo exchange is in flight, k_spmv_remote adds the rest afterwards.
 template <int MODE>
-__global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
+static __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   // double-buffered staging: ONE barrier per tile (the barrier of tile t+1 orders every wave's row
   // phase of tile t before any wave's lane phase of tile t+2, which reuses the buffer)
   __shared__ double scr[2][3][WG];
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
 // on a copy of p spread over 96 / 288 bytes per pose -- a table of 96 / 288 MB at 1M poses, i.e. inside / beyond the
 // 256 MiB Infinity Cache -- to tell gathers served by that cache from gathers served by HBM.
 template <int PSTR = PS>
-__global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
+static __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
   __shared__ double scr[2][3][WG];
   __shared__ double red[8];
   const int tid = threadIdx.x;
@@ -1039,7 +1039,7 @@ struct RemoteArgs {
   int32_t lo;
   const int32_t* done;
 };
-__global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
+static __global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
   __shared__ double red[8];
   if (A.done && *A.done) return;
   double dot = 0.0;
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
 // Jacobi column scaling 1/(1 + ||J col||) from the unscaled diagonal (Ceres
 // TrustRegionMinimizer, iteration 0); 0 on the constant pose.
 // fixed_mask (batched handles: one anchored pose per problem + the padding rows): nullptr = only pose `fixed` is constant
-__global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo, int fixed, int enabled,
+static __global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo, int fixed, int enabled,
                                double* __restrict__ scale, const uint8_t* __restrict__ fixed_mask) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_loc) return;
@@ -1097,7 +1097,7 @@ __global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo,
 // diag_full (METHOD 2): the UNREDUCED squared column norms the LM diagonal is defined on; nullptr = hd's diagonal
 // Batched handles: the trust-region radius is per problem -- prob_radius[prob_of_256[row >> 8]] (problems start at
 // multiples of 256 rows) -- and fixed_mask marks each problem's anchored pose and the padding rows.
-__global__ void k_prepare(const double* __restrict__ hd, const double* __restrict__ diag_full, int n_loc, int lo, int fixed,
+static __global__ void k_prepare(const double* __restrict__ hd, const double* __restrict__ diag_full, int n_loc, int lo, int fixed,
                           double radius, double dmin, double dmax, double* __restrict__ d2, double* __restrict__ minv,
                           const uint8_t* __restrict__ fixed_mask, const int32_t* __restrict__ prob_of_256,
                           const double* __restrict__ prob_radius, double* __restrict__ chain_rec, double* __restrict__ hdd) {
@@ -1145,7 +1145,7 @@ __global__ void k_prepare(const double* __restrict__ hd, const double* __restric
 
 // max_i |g_i| of the UNSCALED gradient g = gs / s over the free parameters (Ceres
 // gradient_max_norm); partial max per workgroup.
-__global__ __launch_bounds__(WG) void k_grad_max(const double* __restrict__ gs, const double* __restrict__ scale,
+static __global__ __launch_bounds__(WG) void k_grad_max(const double* __restrict__ gs, const double* __restrict__ scale,
                                                  int n_loc, int lo, double* __restrict__ part) {
   __shared__ double red[8];
   double m = 0.0;
@@ -1166,7 +1166,7 @@ struct FinArgs {
   int32_t count;
   double* out;
 };
-__global__ __launch_bounds__(WG) void k_finalize(FinArgs A) {
+static __global__ __launch_bounds__(WG) void k_finalize(FinArgs A) {
   __shared__ double red[8];
   for (int k = 0; k < A.count; ++k) {
     double v = 0.0;
@@ -1206,7 +1206,7 @@ __device__ __forceinline__ void minv_apply(const double* __restrict__ minv, int6
 }
 
 // y = 0, r = b, z = M^-1 r, p = z; partials of r.z and b.b
-__global__ __launch_bounds__(WG) void k_cg_init(CgVec V, const double* __restrict__ b, double* __restrict__ part_rz,
+static __global__ __launch_bounds__(WG) void k_cg_init(CgVec V, const double* __restrict__ b, double* __restrict__ part_rz,
                                                 double* __restrict__ part_bb) {
   __shared__ double red[8];
   double rz = 0.0, bb = 0.0;
@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(WG) void k_cg_init(CgVec V, const double* __restric
 }
 
 // scal[0] = r.z, scal[1] = b.b (already reduced over workgroups and ranks)
-__global__ void k_cg_init_fin(CgState* st, const double* __restrict__ scal, double rtol) {
+static __global__ void k_cg_init_fin(CgState* st, const double* __restrict__ scal, double rtol) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     st->rz[0] = scal[0];
     st->rz[1] = scal[0];   // (finite beta for the fused loop's first, no-op direction update)
@@ -1247,7 +1247,7 @@ __global__ void k_cg_init_fin(CgState* st, const double* __restrict__ scal, doub
 }
 
 // alpha = rz / p.Ap ; y += alpha p ; r -= alpha Ap ; z = M^-1 r ; partials r.z, r.r
-__global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, const double* __restrict__ part_pap, int n_pap,
+static __global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, const double* __restrict__ part_pap, int n_pap,
                                                    double* __restrict__ part_rz, double* __restrict__ part_rr) {
   __shared__ double red[8];
   if (V.st->done) return;
@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, const do
 
 // End of a slice of fused-update iterations (k_spmv MODE 5): book the last iteration's partials so that the host sees
 // its iteration count, residual and convergence flag.  One workgroup.
-__global__ __launch_bounds__(WG) void k_cg_book(CgState* st, int parity, const double* __restrict__ part_rz, int n_rz,
+static __global__ __launch_bounds__(WG) void k_cg_book(CgState* st, int parity, const double* __restrict__ part_rz, int n_rz,
                                                 const double* __restrict__ part_rr, int n_rr) {
   __shared__ double red[8];
   if (st->done || !st->pending) return;
@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(WG) void k_cg_book(CgState* st, int parity, const d
 }
 
 // beta = rz_new / rz ; p = z + beta p ; workgroup 0 publishes the new scalars
-__global__ __launch_bounds__(WG) void k_cg_update2(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
+static __global__ __launch_bounds__(WG) void k_cg_update2(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
                                                    const double* __restrict__ part_rr, int n_rr) {
   __shared__ double red[8];
   if (V.st->done) return;
@@ -1363,7 +1363,7 @@ struct GroupPrepArgs {
   int32_t n_loc, lo, B, nb, n_groups;
 };
 
-__global__ __launch_bounds__(WG) void k_prepare_groups(GroupPrepArgs A) {
+static __global__ __launch_bounds__(WG) void k_prepare_groups(GroupPrepArgs A) {
   extern __shared__ double Mall[];  // (WG / L) matrices of nb x (nb + 1)
   // L lanes cooperate on one group: a whole workgroup for big blocks, one wave for small ones (nb <= 24),
   // so that four groups share a workgroup.  Control flow is uniform (same nb everywhere): the barriers
@@ -1455,7 +1455,7 @@ __device__ __forceinline__ double group_apply(const GroupPre& G, int g, int slot
   return z;
 }
 
-__global__ __launch_bounds__(WG) void k_cg_init_g(CgVec V, GroupPre G, const double* __restrict__ b,
+static __global__ __launch_bounds__(WG) void k_cg_init_g(CgVec V, GroupPre G, const double* __restrict__ b,
                                                   double* __restrict__ part_rz, double* __restrict__ part_bb) {
   __shared__ double rb[WG];
   __shared__ double red[8];
@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(WG) void k_cg_init_g(CgVec V, GroupPre G, const dou
   }
 }
 
-__global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int parity, const double* __restrict__ part_pap,
+static __global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int parity, const double* __restrict__ part_pap,
                                                      int n_pap, double* __restrict__ part_rz, double* __restrict__ part_rr) {
   __shared__ double rb[WG];
   __shared__ double red[8];
@@ -1575,7 +1575,7 @@ struct ChainPre {
 
 // Rows whose block (i, i-1) is the sum of several edges' blocks (listed at create; rare): the C part of their record is
 // rewritten as the sum over the run of incidences in incidence order.  One thread per listed row.
-__global__ void k_chain_dupfix(const int32_t* __restrict__ rows, int n_rows, const int32_t* __restrict__ inc_ptr,
+static __global__ void k_chain_dupfix(const int32_t* __restrict__ rows, int n_rows, const int32_t* __restrict__ inc_ptr,
                                const int32_t* __restrict__ inc_col, const double* __restrict__ hoff, int lo,
                                double* __restrict__ rec) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1603,7 +1603,7 @@ __global__ void k_chain_dupfix(const int32_t* __restrict__ rows, int n_rows, con
 //    transposed layout the values of poses j, j + CHUNK, j + 2 CHUNK, ... of one segment are adjacent, i.e. GS / CHUNK
 //    consecutive doubles per (plane, k) -- 32-byte (CHUNK = 2) or 16-byte (CHUNK = 4) pieces instead of 8-byte ones.
 template <int CHUNK>
-__global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len,
+static __global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len,
                                                      double* __restrict__ cw, double* __restrict__ cs) {
   constexpr int PF = 4, GS = 8, RUN = GS / CHUNK;   // RUN adjacent doubles per (plane, k) and group
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1854,7 +1854,7 @@ __device__ __forceinline__ int chain_lds_pos(int e) { return e + e / (3 * CHAIN_
 
 // PCG start-up with the chain preconditioner: r = b, z = M^-1 r, y = 0, p = z; partials of r.z and b.b.
 // One wavefront per 256-row tile; workgroup = 4 waves = 1024 rows.
-__global__ __launch_bounds__(WG) void k_cg_init_c(CgVec V, ChainPre C, const double* __restrict__ b,
+static __global__ __launch_bounds__(WG) void k_cg_init_c(CgVec V, ChainPre C, const double* __restrict__ b,
                                                   double* __restrict__ part_rz, double* __restrict__ part_bb) {
   __shared__ double tile[4][CHAIN_LDS];
   __shared__ double red[8];
@@ -1907,7 +1907,7 @@ __global__ __launch_bounds__(WG) void k_cg_init_c(CgVec V, ChainPre C, const dou
 }
 
 // x += alpha p ; r -= alpha A p ; z = M^-1 r (chain) ; partials of r.z and r.r
-__global__ __launch_bounds__(WG) void k_cg_update1_c(CgVec V, ChainPre C, int parity, const double* __restrict__ part_pap,
+static __global__ __launch_bounds__(WG) void k_cg_update1_c(CgVec V, ChainPre C, int parity, const double* __restrict__ part_pap,
                                                      int n_pap, double* __restrict__ part_rz, double* __restrict__ part_rr) {
   __shared__ double tile[4][CHAIN_LDS];
   __shared__ double red[8];
@@ -2156,7 +2156,7 @@ __device__ __forceinline__ double block_sum_nw(double v, double* sh) {
   }
 }
 template <int CH, int NW>
-__global__ __launch_bounds__(64 * NW) void k_cg_init_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, const double* __restrict__ b,
+static __global__ __launch_bounds__(64 * NW) void k_cg_init_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, const double* __restrict__ b,
                                                    double* __restrict__ part_rz, double* __restrict__ part_bb) {
   constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
   __shared__ double tile[NW][64 * STRIDE];
@@ -2230,13 +2230,13 @@ __global__ __launch_bounds__(64 * NW) void k_cg_init_cl(CgVec V, ChainPre C, int
 
 // x += alpha p ; r -= alpha A p ; z = M^-1 r (lean chain apply) ; partials of r.z and r.r
 #ifdef PGO_PHASE_TIMING
-__device__ unsigned long long g_phase_t[16];
+static __device__ unsigned long long g_phase_t[16];
 #define PGO_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_t[k] = wall_clock64(); } while (0)
 #else
 #define PGO_T(k) do { } while (0)
 #endif
 template <int CH, int NW>
-__global__ __launch_bounds__(64 * NW) void k_cg_update1_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, int parity,
+static __global__ __launch_bounds__(64 * NW) void k_cg_update1_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, int parity,
                                                       const double* __restrict__ part_pap, int n_pap,
                                                       double* __restrict__ part_rz, double* __restrict__ part_rr) {
   constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
@@ -2385,7 +2385,7 @@ __global__ __launch_bounds__(64 * NW) void k_cg_update1_cl(CgVec V, ChainPre C, 
 // k_cg_sr_scal.  u lives in the gather vector (V.p, global indexing), p in V.z, s in `sv`, w in V.ap.
 
 // scal = (gamma, rr, delta) reduced over workgroups and ranks; first != 0: start of a solve (scal[1] = b.b)
-__global__ void k_cg_sr_scal(CgState* st, const double* __restrict__ scal, double rtol, int first) {
+static __global__ void k_cg_sr_scal(CgState* st, const double* __restrict__ scal, double rtol, int first) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double gamma = scal[0], rr = scal[1], delta = scal[2];
   if (first) {
@@ -2416,7 +2416,7 @@ __global__ void k_cg_sr_scal(CgState* st, const double* __restrict__ scal, doubl
 }
 
 template <int CH, int NW>
-__global__ __launch_bounds__(64 * NW) void k_cg_sr_cl(CgVec V, ChainPre C, double* __restrict__ sv, int n_steps, int scan_levels,
+static __global__ __launch_bounds__(64 * NW) void k_cg_sr_cl(CgVec V, ChainPre C, double* __restrict__ sv, int n_steps, int scan_levels,
                                                  double* __restrict__ part_gamma, double* __restrict__ part_rr) {
   constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
   __shared__ double tile[NW][64 * STRIDE];
@@ -2520,7 +2520,7 @@ struct SwitchArrays {
   double* hss;
 };
 
-__global__ void k_switch_scale(SwitchArrays W, int enabled) {
+static __global__ void k_switch_scale(SwitchArrays W, int enabled) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= W.n_edges) return;
   double sg = 1.0;
@@ -2532,7 +2532,7 @@ __global__ void k_switch_scale(SwitchArrays W, int enabled) {
 }
 
 // per LM iteration: elimination coefficients; partial max of the unscaled switch gradient and of sum s^2
-__global__ __launch_bounds__(WG) void k_switch_prepare(SwitchArrays W, const double* __restrict__ jr, double radius, double dmin,
+static __global__ __launch_bounds__(WG) void k_switch_prepare(SwitchArrays W, const double* __restrict__ jr, double radius, double dmin,
                                                        double dmax, double* __restrict__ part_gmax,
                                                        double* __restrict__ part_s2) {
   __shared__ double red[8];
@@ -2570,7 +2570,7 @@ __global__ __launch_bounds__(WG) void k_switch_prepare(SwitchArrays W, const dou
 }
 
 // after the pose solve: back-substitute the switches; partials of the model-decrease terms and of the step norm
-__global__ __launch_bounds__(WG) void k_switch_backsub(SwitchArrays W, const int32_t* __restrict__ ia, const int32_t* __restrict__ ib,
+static __global__ __launch_bounds__(WG) void k_switch_backsub(SwitchArrays W, const int32_t* __restrict__ ia, const int32_t* __restrict__ ib,
                                                        const double* __restrict__ jr, const double* __restrict__ scale,
                                                        const double* __restrict__ yfull, double* __restrict__ part_model,
                                                        double* __restrict__ part_step2) {
@@ -2620,7 +2620,7 @@ struct ProbSums {
   double cost, gmax, xnorm2;
 };
 // one workgroup per problem, fixed summation order (thread-strided partials, then the workgroup tree)
-__global__ __launch_bounds__(WG) void k_prob_reduce(const ProbRange* __restrict__ pr, const double* __restrict__ edge_cost,
+static __global__ __launch_bounds__(WG) void k_prob_reduce(const ProbRange* __restrict__ pr, const double* __restrict__ edge_cost,
                                                     const double* __restrict__ gs, const double* __restrict__ scale,
                                                     const double* __restrict__ x, int lo, ProbSums* __restrict__ out) {
   __shared__ double red[8];
@@ -2647,7 +2647,7 @@ __global__ __launch_bounds__(WG) void k_prob_reduce(const ProbRange* __restrict_
   }
 }
 // x <- cand on the rows of the accepted problems
-__global__ void k_accept_rows(int n_loc, int lo, const int32_t* __restrict__ prob_of_256, const int32_t* __restrict__ accept,
+static __global__ void k_accept_rows(int n_loc, int lo, const int32_t* __restrict__ prob_of_256, const int32_t* __restrict__ accept,
                               const double* __restrict__ cand, double* __restrict__ x) {
   const int64_t n3 = 3 * (int64_t)n_loc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
@@ -2660,7 +2660,7 @@ __global__ void k_accept_rows(int n_loc, int lo, const int32_t* __restrict__ pro
 //     y.(H y) = y.b - y.r - y.(D y)
 // -- three dot products over vectors that are there anyway instead of one more SpMV per LM iteration.  Partials of
 // y.b, y.r and y.(D y) per workgroup.
-__global__ __launch_bounds__(WG) void k_model_terms(int64_t n, const double* __restrict__ y, const double* __restrict__ b,
+static __global__ __launch_bounds__(WG) void k_model_terms(int64_t n, const double* __restrict__ y, const double* __restrict__ b,
                                                     const double* __restrict__ r, const double* __restrict__ d2,
                                                     double* __restrict__ part_yb, double* __restrict__ part_yr,
                                                     double* __restrict__ part_ydy) {
@@ -2683,7 +2683,7 @@ __global__ __launch_bounds__(WG) void k_model_terms(int64_t n, const double* __r
 }
 
 // partials of a.b over n doubles
-__global__ __launch_bounds__(WG) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+static __global__ __launch_bounds__(WG) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
                                             double* __restrict__ part) {
   __shared__ double red[8];
   double s = 0.0;
@@ -2692,10 +2692,10 @@ __global__ __launch_bounds__(WG) void k_dot(int64_t n, const double* __restrict_
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-__global__ void k_flag_to_double(const int* __restrict__ flag, double* __restrict__ out) { out[0] = (double)(*flag); }
+static __global__ void k_flag_to_double(const int* __restrict__ flag, double* __restrict__ out) { out[0] = (double)(*flag); }
 
 // copy the owned part of a local [n x 3] vector into the padded, globally indexed gather vector
-__global__ void k_scatter_owned(int n_loc, int lo, const double* __restrict__ src, double* __restrict__ dst) {
+static __global__ void k_scatter_owned(int n_loc, int lo, const double* __restrict__ src, double* __restrict__ dst) {
   const int64_t n3 = 3 * (int64_t)n_loc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / 3;
@@ -2704,14 +2704,14 @@ __global__ void k_scatter_owned(int n_loc, int lo, const double* __restrict__ sr
 }
 
 // halo exchange helpers: pack rows of the gather vector into a contiguous buffer / scatter them back
-__global__ void k_pack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
+static __global__ void k_pack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
                             double* __restrict__ dst) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n_rows; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t k = i / 3;
     dst[i] = src[PS * (int64_t)rows[k] + (i - 3 * k)];
   }
 }
-__global__ void k_unpack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
+static __global__ void k_unpack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
                               double* __restrict__ dst) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n_rows; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t k = i / 3;
@@ -2720,7 +2720,7 @@ __global__ void k_unpack_rows(int64_t n_rows, const int32_t* __restrict__ rows, 
 }
 
 // candidate = x - S y on the owned rows; partials of |step|^2
-__global__ __launch_bounds__(WG) void k_candidate(int n_loc, int lo, const double* __restrict__ x,
+static __global__ __launch_bounds__(WG) void k_candidate(int n_loc, int lo, const double* __restrict__ x,
                                                   const double* __restrict__ scale, const double* __restrict__ y,
                                                   double* __restrict__ cand, double* __restrict__ part_step2) {
   __shared__ double red[8];
@@ -2736,7 +2736,7 @@ __global__ __launch_bounds__(WG) void k_candidate(int n_loc, int lo, const doubl
 }
 
 // partials of |x|^2 over the owned free parameters (scale == 0 marks the constant pose)
-__global__ __launch_bounds__(WG) void k_xnorm(int n_loc, int lo, const double* __restrict__ x,
+static __global__ __launch_bounds__(WG) void k_xnorm(int n_loc, int lo, const double* __restrict__ x,
                                               const double* __restrict__ scale, double* __restrict__ part) {
   __shared__ double red[8];
   double s2 = 0.0;
