@@ -80,7 +80,8 @@ __device__ __forceinline__ double wave_sum_fixed(double v) {
 }
 
 // one wavefront per aggregate: centre of the aggregate's poses, then the basis planes of its poses
-static __global__ __launch_bounds__(256) void k_coarse_basis(CoarseArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_coarse_basis(CoarseArgs A) {
   const int w = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (w >= A.n_agg) return;
   const int i0 = w * A.agg, i1 = min(A.n_loc, i0 + A.agg);
@@ -125,7 +126,8 @@ __device__ __forceinline__ void coarse_accumulate(double (&C)[9], const PBasis& 
 // partial 3x3 sums are added in a fixed tree -- the same bits on every run.  Block (I, I) also takes the diagonal blocks
 // H_ii + D'D of its poses.  Writes the block into the dense matrix and, for blocks on the block diagonal of the 32 x 32
 // partition, into `dwork`.
-static __global__ __launch_bounds__(256) void k_coarse_assemble(CoarseArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_coarse_assemble(CoarseArgs A) {
   const int b = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (b >= A.n_cb) return;
   const int I = A.cb_i[b], J = A.cb_j[b];
@@ -163,7 +165,8 @@ static __global__ __launch_bounds__(256) void k_coarse_assemble(CoarseArgs A) {
 }
 
 // identity on the padding rows K .. Kp-1 of the (zeroed) coarse matrix and of dwork
-static __global__ void k_coarse_pad(double* __restrict__ cap, double* __restrict__ dwork, int K, int Kp) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_coarse_pad(double* __restrict__ cap, double* __restrict__ dwork, int K, int Kp) {
   const int p = K + blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= Kp) return;
   cap[(int64_t)p * Kp + p] = 1.0;
@@ -171,7 +174,8 @@ static __global__ void k_coarse_pad(double* __restrict__ cap, double* __restrict
 }
 
 // r_c = P' r: one wavefront per aggregate, fixed order
-static __global__ __launch_bounds__(256) void k_coarse_restrict(int n_loc, int agg, int n_agg, const double* __restrict__ pb,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_coarse_restrict(int n_loc, int agg, int n_agg, const double* __restrict__ pb,
                                                          const double* __restrict__ r, double* __restrict__ rc,
                                                          const int32_t* __restrict__ done) {
   if (done && *done) return;
@@ -198,7 +202,8 @@ static __global__ __launch_bounds__(256) void k_coarse_restrict(int n_loc, int a
 }
 
 // z += P e_c and the same into the gather vector p (the PCG start-up, where p = z); skipped as a whole when the level is off
-static __global__ __launch_bounds__(256) void k_coarse_prolong(int n_loc, int agg, const double* __restrict__ pb, const double* __restrict__ ec,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_coarse_prolong(int n_loc, int agg, const double* __restrict__ pb, const double* __restrict__ ec,
                                                         double* __restrict__ z, double* __restrict__ p, const int32_t* __restrict__ ok) {
   if (!*ok) return;
   const int64_t n = n_loc;
@@ -220,13 +225,15 @@ static __global__ __launch_bounds__(256) void k_coarse_prolong(int n_loc, int ag
   }
 }
 
-static __global__ void k_fill(double* __restrict__ x, int64_t n, double v) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_fill(double* __restrict__ x, int64_t n, double v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = v;
 }
 
 // explicit inverse of the coarse matrix, Ainv = N'N (N = L^-1, lower triangular), for small orders: one thread per entry
-static __global__ __launch_bounds__(256) void k_coarse_ainv(const double* __restrict__ Nm, int Kp, double* __restrict__ Ainv) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_coarse_ainv(const double* __restrict__ Nm, int Kp, double* __restrict__ Ainv) {
   const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
   if (j >= Kp) return;
   double s = 0.0;
@@ -236,7 +243,8 @@ static __global__ __launch_bounds__(256) void k_coarse_ainv(const double* __rest
 
 // the level is usable iff a probe of the factor is finite: x = Ainv 1 (explicit inverse) or x = N'(N 1) computed by the
 // caller with k_tri_apply; one workgroup
-static __global__ __launch_bounds__(256) void k_coarse_check(const double* __restrict__ x, int K, int32_t* __restrict__ ok) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_coarse_check(const double* __restrict__ x, int K, int32_t* __restrict__ ok) {
   __shared__ int bad;
   if (threadIdx.x == 0) bad = 0;
   __syncthreads();
@@ -249,7 +257,8 @@ static __global__ __launch_bounds__(256) void k_coarse_check(const double* __res
 
 // e_c = Ainv r_c (dense, symmetric, order Kp <= 1024): one wavefront per row, four rows per workgroup; the workgroup's
 // share of r_c . e_c goes to dot_part[blockIdx.x] (fixed order).  Level off: e_c = 0, partials 0.
-static __global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict__ Ainv, int Kp, const double* __restrict__ rc,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict__ Ainv, int Kp, const double* __restrict__ rc,
                                                        double* __restrict__ ec, double* __restrict__ dot_part,
                                                        const int32_t* __restrict__ ok, const int32_t* __restrict__ done) {
   __shared__ double sh[4];
@@ -270,17 +279,82 @@ static __global__ __launch_bounds__(256) void k_coarse_matvec(const double* __re
   if (threadIdx.x == 0) dot_part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// large orders, after the two triangular products: partials of r_c . e_c, 256 entries per workgroup; level off: e_c = 0
-static __global__ __launch_bounds__(256) void k_coarse_dot(int Kp, const double* __restrict__ rc, double* __restrict__ ec,
-                                                    double* __restrict__ dot_part, const int32_t* __restrict__ ok,
-                                                    const int32_t* __restrict__ done) {
+// ---- large coarse orders: the two triangular products N'(N r_c) cut into tiles of 32 rows x TRI_CW columns (N x) /
+// TRI_CW rows x 32 columns (N' y), one workgroup each, so that a few hundred workgroups share the factor's 88 MB (order
+// 4689) evenly -- with one workgroup per block row (k_tri_apply) the last rows set the pace.  Partial sums are written per
+// tile and added in tile order by the consumer: a fixed order, bitwise reproducible.
+constexpr int TRI_CW = 512;
+// tiles of y = N x: tile list entry t = (block row b, column chunk j); part_a[(b * n_chunk + j) * 32 + row]
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_tri_tiles_a(const double* __restrict__ Nm, int ld, const int2* __restrict__ tiles,
+                                                            const double* __restrict__ x, double* __restrict__ part_a, int n_chunk,
+                                                            const int32_t* __restrict__ done) {
+  if (done && *done) return;
+  const int2 t = tiles[blockIdx.x];
+  const int b = t.x, j = t.y;
+  const int r = threadIdx.x >> 3, p = threadIdx.x & 7;
+  const int c0 = j * TRI_CW, c1 = min(32 * (b + 1), c0 + TRI_CW);
+  const double* row = Nm + (int64_t)(32 * b + r) * ld;
+  double s = 0.0;
+#pragma unroll 8
+  for (int c = c0 + p; c < c1; c += 8) s += row[c] * x[c];
+  s += __shfl_xor(s, 1, 8);
+  s += __shfl_xor(s, 2, 8);
+  s += __shfl_xor(s, 4, 8);
+  if (p == 0) part_a[((int64_t)b * n_chunk + j) * 32 + r] = s;
+}
+// tiles of z = N' y with y = the sum of part_a's chunks: tile (column block b, row chunk i): rows [i TRI_CW, (i + 1) TRI_CW)
+// from 32 b on; part_b[(b * n_chunk + i) * 32 + column]
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_tri_tiles_b(const double* __restrict__ Nm, int ld, int nb, const int2* __restrict__ tiles,
+                                                            const double* __restrict__ part_a, double* __restrict__ part_b, int n_chunk,
+                                                            const int32_t* __restrict__ done) {
+  __shared__ double ys[TRI_CW];
+  __shared__ double red[8][32];
+  if (done && *done) return;
+  const int2 t = tiles[blockIdx.x];
+  const int b = t.x, i = t.y;
+  const int r0 = max(32 * b, i * TRI_CW), r1 = min(32 * nb, (i + 1) * TRI_CW);
+  // y of the chunk's rows: chunks 0 .. (columns of that block row) in order
+  for (int k = threadIdx.x; k < r1 - r0; k += 256) {
+    const int rr = r0 + k, br = rr >> 5;
+    const int nch = (32 * (br + 1) + TRI_CW - 1) / TRI_CW;
+    double v = 0.0;
+    for (int jj = 0; jj < nch; ++jj) v += part_a[((int64_t)br * n_chunk + jj) * 32 + (rr & 31)];
+    ys[k] = v;
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 31, p = threadIdx.x >> 5;
+  double s = 0.0;
+#pragma unroll 8
+  for (int rr = r0 + p; rr < r1; rr += 8) s += Nm[(int64_t)rr * ld + 32 * b + c] * ys[rr - r0];
+  red[p][c] = s;
+  __syncthreads();
+  if (p == 0) {
+    double v = red[0][c];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) v += red[q][c];
+    part_b[((int64_t)b * n_chunk + i) * 32 + c] = v;
+  }
+}
+// e_c = the sum of part_b's chunks (level off: 0) and the partials of r_c . e_c, 256 entries per workgroup
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_tri_finish(int Kp, int nb, int n_chunk, const double* __restrict__ part_b,
+                                                           const double* __restrict__ rc, double* __restrict__ ec,
+                                                           double* __restrict__ dot_part, const int32_t* __restrict__ ok,
+                                                           const int32_t* __restrict__ done) {
   __shared__ double red[8];
   if (done && *done) return;
   const int k = blockIdx.x * 256 + threadIdx.x;
   double v = 0.0;
   if (k < Kp) {
-    if (!*ok) ec[k] = 0.0;
-    else v = rc[k] * ec[k];
+    double e = 0.0;
+    if (*ok) {
+      const int b = k >> 5;
+      for (int i = (32 * b) / TRI_CW; i * TRI_CW < 32 * nb; ++i) e += part_b[((int64_t)b * n_chunk + i) * 32 + (k & 31)];
+    }
+    ec[k] = e;
+    v = rc[k] * e;
   }
   v = block_sum_bcast(v, red);
   if (threadIdx.x == 0) dot_part[blockIdx.x] = v;
@@ -288,7 +362,8 @@ static __global__ __launch_bounds__(256) void k_coarse_dot(int Kp, const double*
 
 // k_cg_update2 with the prolongation folded in: beta = rz_new / rz ; p = (z + P e_c) + beta p, where rz_new sums the
 // one-level partials AND the coarse level's partials of r_c . e_c (n_rz covers both).  Workgroup 0 publishes the scalars.
-static __global__ __launch_bounds__(WG) void k_cg_update2c(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_cg_update2c(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
                                                     const double* __restrict__ part_rr, int n_rr, int agg,
                                                     const double* __restrict__ pb, const double* __restrict__ ec) {
   __shared__ double red[8];

@@ -104,7 +104,8 @@ __device__ __forceinline__ void dlr_blocks(const DlrArgs& A, int64_t e, const do
   }
 }
 
-static __global__ void k_dlr_setup(DlrArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_dlr_setup(DlrArgs A) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < A.n) {
     const int i = idx;
@@ -172,7 +173,8 @@ static __global__ void k_dlr_setup(DlrArgs A) {
 // Block LDL' of the block-tridiagonal T, one wavefront (every lane runs the same recurrence; lane 0 stores).  The input
 // records pass through LDS in chunks of 128 poses, the next chunk is fetched while the current one is factorised: the
 // 3x3 recurrence itself (a cofactor inverse and two 3x3 products per pose, ~0.1 us) is the critical path.
-static __global__ __launch_bounds__(64) void k_dlr_factor(const double* __restrict__ trec_all, int n_all, double* __restrict__ fac_all, DlrArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(64) void k_dlr_factor(const double* __restrict__ trec_all, int n_all, double* __restrict__ fac_all, DlrArgs A) {
   constexpr int CH = 128;
   __shared__ double buf[2][CH * DLR_REC];
   const int lane = threadIdx.x;
@@ -274,7 +276,8 @@ struct DlrColsArgs {
 };
 
 // prefix products of one segment per thread: the first half of the workgroup forward (G), the second half backward (Gb)
-static __global__ __launch_bounds__(512) void k_dlr_prefix(const double* __restrict__ fac, int n, int nseg, int seglen, double* __restrict__ pre) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(512) void k_dlr_prefix(const double* __restrict__ fac, int n, int nseg, int seglen, double* __restrict__ pre) {
   const int t = threadIdx.x;
   const int half = blockDim.x >> 1;
   const bool back = t >= half;
@@ -347,7 +350,8 @@ __device__ __forceinline__ DlrCol dlr_col(const DlrColsArgs& A, int col) {
   return c;
 }
 
-static __global__ __launch_bounds__(256) void k_dlr_fwd(DlrColsArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_dlr_fwd(DlrColsArgs A) {
   constexpr int CH = 64;
   __shared__ double fb[CH * DLR_REC];
   __shared__ double rv[CH * 3];   // the dense right-hand side of the chunk (read by the one lane that owns that column: from
@@ -396,7 +400,8 @@ static __global__ __launch_bounds__(256) void k_dlr_fwd(DlrColsArgs A) {
   }
 }
 
-static __global__ __launch_bounds__(256) void k_dlr_mid(DlrColsArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_dlr_mid(DlrColsArgs A) {
   constexpr int CH = 64;
   __shared__ double fb[(CH + 1) * DLR_REC];
   __shared__ double gb[CH * 9];
@@ -480,7 +485,8 @@ static __global__ __launch_bounds__(256) void k_dlr_mid(DlrColsArgs A) {
   }
 }
 
-static __global__ __launch_bounds__(256) void k_dlr_fix(DlrColsArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_dlr_fix(DlrColsArgs A) {
   __shared__ double gbs[64 * 9];
   const int col = blockIdx.x * 256 + threadIdx.x;
   const int s = blockIdx.y;
@@ -570,7 +576,8 @@ struct DlrSepArgs {
   double* Wm;           // [nU][ld]
 };
 
-static __global__ __launch_bounds__(256) void k_dlr_sep_system(DlrSepArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_dlr_sep_system(DlrSepArgs A) {
   __shared__ double Ab[DLR_MAX_U * 2 * DLR_MAX_U];   // [S | I], row stride 2 nU
   const int tid = threadIdx.x, nU = A.nU, w2 = 2 * nU;
   for (int e = tid; e < nU * nU; e += 256) {
@@ -609,7 +616,8 @@ static __global__ __launch_bounds__(256) void k_dlr_sep_system(DlrSepArgs A) {
 }
 
 // w_j = S^-1 (Ms z_s - C_s z_{s-1} - C_{s+1}' z_{s+1}) for the columns j < ncols of X
-static __global__ __launch_bounds__(256) void k_dlr_sep_w(DlrSepArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_dlr_sep_w(DlrSepArgs A) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= A.ncols) return;
   const int nU = A.nU;
@@ -652,7 +660,8 @@ static __global__ __launch_bounds__(256) void k_dlr_sep_w(DlrSepArgs A) {
 // z_j -= Y w_j (piece rows; Y is zero on the separator rows), z_j = w_j on the separator rows.  A thread = one column, a
 // workgroup = 64 rows of it (w_j in registers, the rows of Y staged in LDS, 8 rows read and written at a time); with a
 // single column: one thread per row instead
-static __global__ __launch_bounds__(256) void k_dlr_sep_apply(DlrSepArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_dlr_sep_apply(DlrSepArgs A) {
   __shared__ double Ys[64 * DLR_MAX_U];
   __shared__ int sepu[64];   // row -> entry of w that replaces it (-1: a piece row)
   const int nU = A.nU;
@@ -729,7 +738,8 @@ struct DlrSolve1Args {
   int32_t yld;
   const double* Sinv;
 };
-static __global__ __launch_bounds__(256) void k_dlr_solve1(DlrSolve1Args A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_dlr_solve1(DlrSolve1Args A) {
   __shared__ double sa[2][256 * 3];
   __shared__ double sF[2][256 * 9];
   __shared__ double sg[DLR_MAX_U], sw[DLR_MAX_U];
@@ -878,7 +888,8 @@ static __global__ __launch_bounds__(256) void k_dlr_solve1(DlrSolve1Args A) {
 // capacitance matrix I + V Z (row p = row of V, column q = column of Z), its diagonal blocks once more in `dwork`, and
 // the right-hand side V t (t = column K of Z); padding rows / columns K .. Kp-1 = identity.
 // grid (ld / 256 rounded up, Kp), block 256.
-static __global__ __launch_bounds__(256) void k_dlr_cap(DlrArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_dlr_cap(DlrArgs A) {
   const int p = blockIdx.y;
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q > A.K && q >= A.Kp) return;
@@ -924,7 +935,8 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // sr
   return __hiloint2double(hi, lo);
 }
 
-static __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict__ Cm, double* __restrict__ Nm, double* __restrict__ dwork,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __restrict__ Cm, double* __restrict__ Nm, double* __restrict__ dwork,
                                                               int ld, int nb, int kb) {
   extern __shared__ double sm[];
   double* Dm = sm;                 // [32][33]
@@ -1158,7 +1170,8 @@ static __global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(double* __re
 
 // y = N x (trans = 0: one workgroup per block row) or y = N' x (trans = 1: one workgroup per block column), N lower
 // block-triangular with full 32 x 32 blocks (zeros above the diagonal inside the diagonal blocks)
-static __global__ __launch_bounds__(256) void k_tri_apply(const double* __restrict__ Nm, int ld, int nb, const double* __restrict__ x,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_tri_apply(const double* __restrict__ Nm, int ld, int nb, const double* __restrict__ x,
                                                     double* __restrict__ y, int trans) {
   __shared__ double red[8][32];
   const int tid = threadIdx.x;
@@ -1190,7 +1203,8 @@ static __global__ __launch_bounds__(256) void k_tri_apply(const double* __restri
 }
 
 // w[p] = (row p of V) . x  for a single vector x given as column `xcol` of X ([3n][xld]); rows K .. Kp-1 = 0
-static __global__ void k_dlr_vdot(DlrArgs A, const double* __restrict__ X, int xld, int xcol, double* __restrict__ w) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_dlr_vdot(DlrArgs A, const double* __restrict__ X, int xld, int xcol, double* __restrict__ w) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= A.Kp) return;
   double val = 0.0;
@@ -1206,7 +1220,8 @@ static __global__ void k_dlr_vdot(DlrArgs A, const double* __restrict__ X, int x
 }
 
 // y[row] (+)= t[row] - sum_q Z[row][q] w[q]; one wavefront per row, t = column tcol of Tm ([rows][tld])
-static __global__ __launch_bounds__(256) void k_dlr_combine(const double* __restrict__ Z, int ld, int K, const double* __restrict__ w,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(256) void k_dlr_combine(const double* __restrict__ Z, int ld, int K, const double* __restrict__ w,
                                                       const double* __restrict__ Tm, int tld, int tcol, int nrows,
                                                       double* __restrict__ y, int add) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1224,7 +1239,8 @@ static __global__ __launch_bounds__(256) void k_dlr_combine(const double* __rest
 }
 
 // r = b - Ap
-static __global__ void k_dlr_resid(int64_t n, const double* __restrict__ b, const double* __restrict__ ap, double* __restrict__ r) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_dlr_resid(int64_t n, const double* __restrict__ b, const double* __restrict__ ap, double* __restrict__ r) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) r[i] = b[i] - ap[i];
 }

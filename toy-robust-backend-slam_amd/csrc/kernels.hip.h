@@ -237,7 +237,7 @@ __device__ __forceinline__ Chol3 chol3(double w00, double w01, double w02, doubl
 // One lane per edge.  Algorithmic bytes per edge: 8 (ia,ib) + 24 (meas) + 1 (flags) +
 // 48 (two poses) read, 112 written with the Jacobian, 0 without (INFO: + 48 read, 128 written).
 template <bool WITH_JAC, bool INFO>
-static __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict__ jr,
+__global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __restrict__ jr,
                                                   double* __restrict__ cost_part, int* __restrict__ bad) {
   constexpr int RN = RecLayout<INFO>::N, RL = RecLayout<INFO>::LDS;
   __shared__ double stage[WITH_JAC ? WG * RL : 1];
@@ -418,7 +418,8 @@ static __global__ __launch_bounds__(WG) void k_edge_eval(EdgeArgs A, double* __r
 // compute_edge_mahalanobis (src/layer_manager.cpp:230-282) for every local edge that this rank counts (flags bit1):
 // m = r' Omega r of the PLAIN residual r = (ex, ey, asin(clamp(sin delta))), clamped at 0, written to the caller's edge
 // index.  Any symmetric Omega (no factorisation).  57 B read + 48 B information + 8 B written per edge.
-static __global__ __launch_bounds__(WG) void k_edge_chi2(EdgeArgs A, const int32_t* __restrict__ orig_edge, double* __restrict__ out) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_edge_chi2(EdgeArgs A, const int32_t* __restrict__ orig_edge, double* __restrict__ out) {
   const int64_t ne = A.n_edges;
   for (int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x; e < ne; e += (int64_t)gridDim.x * WG) {
     if (!(A.flags[e] & 2u)) continue;
@@ -602,7 +603,7 @@ __device__ __forceinline__ void asm_store_row(const AsmArgs& A, int c, int row, 
 // a tile cost four dependent round trips (tile_row -> inc_ptr -> inc_edge -> record, plus an 8-step search for the row)
 // and two barriers: 433 us at 1M poses for 1.83 GB of traffic.
 template <bool SC, bool INFO>
-static __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
+__global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
   static_assert(!(SC && INFO), "switchable constraints have no information-weighted form here");
   constexpr int NS = SC ? 15 : 9;  // staged values per incidence
   __shared__ double scr[2][NS][WG];
@@ -733,7 +734,7 @@ struct SpmvArgs {
 // MODE 4 = the part of the product that needs OWNED columns only (blocks whose column lies on another rank contribute
 // 0 and are not loaded): it runs while the halo exchange is in flight, k_spmv_remote adds the rest afterwards.
 template <int MODE>
-static __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
+__global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
   // double-buffered staging: ONE barrier per tile (the barrier of tile t+1 orders every wave's row
   // phase of tile t before any wave's lane phase of tile t+2, which reuses the buffer)
   __shared__ double scr[2][3][WG];
@@ -926,7 +927,7 @@ static __global__ __launch_bounds__(WG) void k_spmv_t(SpmvArgs A) {
 // on a copy of p spread over 96 / 288 bytes per pose -- a table of 96 / 288 MB at 1M poses, i.e. inside / beyond the
 // 256 MiB Infinity Cache -- to tell gathers served by that cache from gathers served by HBM.
 template <int PSTR = PS>
-static __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
+__global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
   __shared__ double scr[2][3][WG];
   __shared__ double red[8];
   const int tid = threadIdx.x;
@@ -1039,7 +1040,8 @@ struct RemoteArgs {
   int32_t lo;
   const int32_t* done;
 };
-static __global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
   __shared__ double red[8];
   if (A.done && *A.done) return;
   double dot = 0.0;
@@ -1073,7 +1075,8 @@ static __global__ __launch_bounds__(WG) void k_spmv_remote(RemoteArgs A) {
 // Jacobi column scaling 1/(1 + ||J col||) from the unscaled diagonal (Ceres
 // TrustRegionMinimizer, iteration 0); 0 on the constant pose.
 // fixed_mask (batched handles: one anchored pose per problem + the padding rows): nullptr = only pose `fixed` is constant
-static __global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo, int fixed, int enabled,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, int lo, int fixed, int enabled,
                                double* __restrict__ scale, const uint8_t* __restrict__ fixed_mask) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_loc) return;
@@ -1097,7 +1100,8 @@ static __global__ void k_jacobi_scale(const double* __restrict__ hd, int n_loc, 
 // diag_full (METHOD 2): the UNREDUCED squared column norms the LM diagonal is defined on; nullptr = hd's diagonal
 // Batched handles: the trust-region radius is per problem -- prob_radius[prob_of_256[row >> 8]] (problems start at
 // multiples of 256 rows) -- and fixed_mask marks each problem's anchored pose and the padding rows.
-static __global__ void k_prepare(const double* __restrict__ hd, const double* __restrict__ diag_full, int n_loc, int lo, int fixed,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_prepare(const double* __restrict__ hd, const double* __restrict__ diag_full, int n_loc, int lo, int fixed,
                           double radius, double dmin, double dmax, double* __restrict__ d2, double* __restrict__ minv,
                           const uint8_t* __restrict__ fixed_mask, const int32_t* __restrict__ prob_of_256,
                           const double* __restrict__ prob_radius, double* __restrict__ chain_rec, double* __restrict__ hdd) {
@@ -1145,7 +1149,8 @@ static __global__ void k_prepare(const double* __restrict__ hd, const double* __
 
 // max_i |g_i| of the UNSCALED gradient g = gs / s over the free parameters (Ceres
 // gradient_max_norm); partial max per workgroup.
-static __global__ __launch_bounds__(WG) void k_grad_max(const double* __restrict__ gs, const double* __restrict__ scale,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_grad_max(const double* __restrict__ gs, const double* __restrict__ scale,
                                                  int n_loc, int lo, double* __restrict__ part) {
   __shared__ double red[8];
   double m = 0.0;
@@ -1166,7 +1171,8 @@ struct FinArgs {
   int32_t count;
   double* out;
 };
-static __global__ __launch_bounds__(WG) void k_finalize(FinArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_finalize(FinArgs A) {
   __shared__ double red[8];
   for (int k = 0; k < A.count; ++k) {
     double v = 0.0;
@@ -1206,7 +1212,8 @@ __device__ __forceinline__ void minv_apply(const double* __restrict__ minv, int6
 }
 
 // y = 0, r = b, z = M^-1 r, p = z; partials of r.z and b.b
-static __global__ __launch_bounds__(WG) void k_cg_init(CgVec V, const double* __restrict__ b, double* __restrict__ part_rz,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_cg_init(CgVec V, const double* __restrict__ b, double* __restrict__ part_rz,
                                                 double* __restrict__ part_bb) {
   __shared__ double red[8];
   double rz = 0.0, bb = 0.0;
@@ -1232,7 +1239,8 @@ static __global__ __launch_bounds__(WG) void k_cg_init(CgVec V, const double* __
 }
 
 // scal[0] = r.z, scal[1] = b.b (already reduced over workgroups and ranks)
-static __global__ void k_cg_init_fin(CgState* st, const double* __restrict__ scal, double rtol) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_cg_init_fin(CgState* st, const double* __restrict__ scal, double rtol) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     st->rz[0] = scal[0];
     st->rz[1] = scal[0];   // (finite beta for the fused loop's first, no-op direction update)
@@ -1247,7 +1255,8 @@ static __global__ void k_cg_init_fin(CgState* st, const double* __restrict__ sca
 }
 
 // alpha = rz / p.Ap ; y += alpha p ; r -= alpha Ap ; z = M^-1 r ; partials r.z, r.r
-static __global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, const double* __restrict__ part_pap, int n_pap,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, const double* __restrict__ part_pap, int n_pap,
                                                    double* __restrict__ part_rz, double* __restrict__ part_rr) {
   __shared__ double red[8];
   if (V.st->done) return;
@@ -1290,7 +1299,8 @@ static __global__ __launch_bounds__(WG) void k_cg_update1(CgVec V, int parity, c
 
 // End of a slice of fused-update iterations (k_spmv MODE 5): book the last iteration's partials so that the host sees
 // its iteration count, residual and convergence flag.  One workgroup.
-static __global__ __launch_bounds__(WG) void k_cg_book(CgState* st, int parity, const double* __restrict__ part_rz, int n_rz,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_cg_book(CgState* st, int parity, const double* __restrict__ part_rz, int n_rz,
                                                 const double* __restrict__ part_rr, int n_rr) {
   __shared__ double red[8];
   if (st->done || !st->pending) return;
@@ -1306,7 +1316,8 @@ static __global__ __launch_bounds__(WG) void k_cg_book(CgState* st, int parity, 
 }
 
 // beta = rz_new / rz ; p = z + beta p ; workgroup 0 publishes the new scalars
-static __global__ __launch_bounds__(WG) void k_cg_update2(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_cg_update2(CgVec V, int parity, const double* __restrict__ part_rz, int n_rz,
                                                    const double* __restrict__ part_rr, int n_rr) {
   __shared__ double red[8];
   if (V.st->done) return;
@@ -1363,7 +1374,8 @@ struct GroupPrepArgs {
   int32_t n_loc, lo, B, nb, n_groups;
 };
 
-static __global__ __launch_bounds__(WG) void k_prepare_groups(GroupPrepArgs A) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_prepare_groups(GroupPrepArgs A) {
   extern __shared__ double Mall[];  // (WG / L) matrices of nb x (nb + 1)
   // L lanes cooperate on one group: a whole workgroup for big blocks, one wave for small ones (nb <= 24),
   // so that four groups share a workgroup.  Control flow is uniform (same nb everywhere): the barriers
@@ -1455,7 +1467,8 @@ __device__ __forceinline__ double group_apply(const GroupPre& G, int g, int slot
   return z;
 }
 
-static __global__ __launch_bounds__(WG) void k_cg_init_g(CgVec V, GroupPre G, const double* __restrict__ b,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_cg_init_g(CgVec V, GroupPre G, const double* __restrict__ b,
                                                   double* __restrict__ part_rz, double* __restrict__ part_bb) {
   __shared__ double rb[WG];
   __shared__ double red[8];
@@ -1490,7 +1503,8 @@ static __global__ __launch_bounds__(WG) void k_cg_init_g(CgVec V, GroupPre G, co
   }
 }
 
-static __global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int parity, const double* __restrict__ part_pap,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_cg_update1_g(CgVec V, GroupPre G, int parity, const double* __restrict__ part_pap,
                                                      int n_pap, double* __restrict__ part_rz, double* __restrict__ part_rr) {
   __shared__ double rb[WG];
   __shared__ double red[8];
@@ -1575,7 +1589,8 @@ struct ChainPre {
 
 // Rows whose block (i, i-1) is the sum of several edges' blocks (listed at create; rare): the C part of their record is
 // rewritten as the sum over the run of incidences in incidence order.  One thread per listed row.
-static __global__ void k_chain_dupfix(const int32_t* __restrict__ rows, int n_rows, const int32_t* __restrict__ inc_ptr,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_chain_dupfix(const int32_t* __restrict__ rows, int n_rows, const int32_t* __restrict__ inc_ptr,
                                const int32_t* __restrict__ inc_col, const double* __restrict__ hoff, int lo,
                                double* __restrict__ rec) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1603,7 +1618,7 @@ static __global__ void k_chain_dupfix(const int32_t* __restrict__ rows, int n_ro
 //    transposed layout the values of poses j, j + CHUNK, j + 2 CHUNK, ... of one segment are adjacent, i.e. GS / CHUNK
 //    consecutive doubles per (plane, k) -- 32-byte (CHUNK = 2) or 16-byte (CHUNK = 4) pieces instead of 8-byte ones.
 template <int CHUNK>
-static __global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len,
+__global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len,
                                                      double* __restrict__ cw, double* __restrict__ cs) {
   constexpr int PF = 4, GS = 8, RUN = GS / CHUNK;   // RUN adjacent doubles per (plane, k) and group
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1854,7 +1869,8 @@ __device__ __forceinline__ int chain_lds_pos(int e) { return e + e / (3 * CHAIN_
 
 // PCG start-up with the chain preconditioner: r = b, z = M^-1 r, y = 0, p = z; partials of r.z and b.b.
 // One wavefront per 256-row tile; workgroup = 4 waves = 1024 rows.
-static __global__ __launch_bounds__(WG) void k_cg_init_c(CgVec V, ChainPre C, const double* __restrict__ b,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_cg_init_c(CgVec V, ChainPre C, const double* __restrict__ b,
                                                   double* __restrict__ part_rz, double* __restrict__ part_bb) {
   __shared__ double tile[4][CHAIN_LDS];
   __shared__ double red[8];
@@ -1907,7 +1923,8 @@ static __global__ __launch_bounds__(WG) void k_cg_init_c(CgVec V, ChainPre C, co
 }
 
 // x += alpha p ; r -= alpha A p ; z = M^-1 r (chain) ; partials of r.z and r.r
-static __global__ __launch_bounds__(WG) void k_cg_update1_c(CgVec V, ChainPre C, int parity, const double* __restrict__ part_pap,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_cg_update1_c(CgVec V, ChainPre C, int parity, const double* __restrict__ part_pap,
                                                      int n_pap, double* __restrict__ part_rz, double* __restrict__ part_rr) {
   __shared__ double tile[4][CHAIN_LDS];
   __shared__ double red[8];
@@ -2156,7 +2173,7 @@ __device__ __forceinline__ double block_sum_nw(double v, double* sh) {
   }
 }
 template <int CH, int NW>
-static __global__ __launch_bounds__(64 * NW) void k_cg_init_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, const double* __restrict__ b,
+__global__ __launch_bounds__(64 * NW) void k_cg_init_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, const double* __restrict__ b,
                                                    double* __restrict__ part_rz, double* __restrict__ part_bb) {
   constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
   __shared__ double tile[NW][64 * STRIDE];
@@ -2236,7 +2253,7 @@ static __device__ unsigned long long g_phase_t[16];
 #define PGO_T(k) do { } while (0)
 #endif
 template <int CH, int NW>
-static __global__ __launch_bounds__(64 * NW) void k_cg_update1_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, int parity,
+__global__ __launch_bounds__(64 * NW) void k_cg_update1_cl(CgVec V, ChainPre C, int n_steps, int scan_levels, int parity,
                                                       const double* __restrict__ part_pap, int n_pap,
                                                       double* __restrict__ part_rz, double* __restrict__ part_rr) {
   constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
@@ -2385,7 +2402,8 @@ static __global__ __launch_bounds__(64 * NW) void k_cg_update1_cl(CgVec V, Chain
 // k_cg_sr_scal.  u lives in the gather vector (V.p, global indexing), p in V.z, s in `sv`, w in V.ap.
 
 // scal = (gamma, rr, delta) reduced over workgroups and ranks; first != 0: start of a solve (scal[1] = b.b)
-static __global__ void k_cg_sr_scal(CgState* st, const double* __restrict__ scal, double rtol, int first) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_cg_sr_scal(CgState* st, const double* __restrict__ scal, double rtol, int first) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double gamma = scal[0], rr = scal[1], delta = scal[2];
   if (first) {
@@ -2416,7 +2434,7 @@ static __global__ void k_cg_sr_scal(CgState* st, const double* __restrict__ scal
 }
 
 template <int CH, int NW>
-static __global__ __launch_bounds__(64 * NW) void k_cg_sr_cl(CgVec V, ChainPre C, double* __restrict__ sv, int n_steps, int scan_levels,
+__global__ __launch_bounds__(64 * NW) void k_cg_sr_cl(CgVec V, ChainPre C, double* __restrict__ sv, int n_steps, int scan_levels,
                                                  double* __restrict__ part_gamma, double* __restrict__ part_rr) {
   constexpr int TILE = 64 * CH, STRIDE = 3 * CH + 1, NV = 3 * CH;
   __shared__ double tile[NW][64 * STRIDE];
@@ -2520,7 +2538,8 @@ struct SwitchArrays {
   double* hss;
 };
 
-static __global__ void k_switch_scale(SwitchArrays W, int enabled) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_switch_scale(SwitchArrays W, int enabled) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= W.n_edges) return;
   double sg = 1.0;
@@ -2532,7 +2551,8 @@ static __global__ void k_switch_scale(SwitchArrays W, int enabled) {
 }
 
 // per LM iteration: elimination coefficients; partial max of the unscaled switch gradient and of sum s^2
-static __global__ __launch_bounds__(WG) void k_switch_prepare(SwitchArrays W, const double* __restrict__ jr, double radius, double dmin,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_switch_prepare(SwitchArrays W, const double* __restrict__ jr, double radius, double dmin,
                                                        double dmax, double* __restrict__ part_gmax,
                                                        double* __restrict__ part_s2) {
   __shared__ double red[8];
@@ -2570,7 +2590,8 @@ static __global__ __launch_bounds__(WG) void k_switch_prepare(SwitchArrays W, co
 }
 
 // after the pose solve: back-substitute the switches; partials of the model-decrease terms and of the step norm
-static __global__ __launch_bounds__(WG) void k_switch_backsub(SwitchArrays W, const int32_t* __restrict__ ia, const int32_t* __restrict__ ib,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_switch_backsub(SwitchArrays W, const int32_t* __restrict__ ia, const int32_t* __restrict__ ib,
                                                        const double* __restrict__ jr, const double* __restrict__ scale,
                                                        const double* __restrict__ yfull, double* __restrict__ part_model,
                                                        double* __restrict__ part_step2) {
@@ -2620,7 +2641,8 @@ struct ProbSums {
   double cost, gmax, xnorm2;
 };
 // one workgroup per problem, fixed summation order (thread-strided partials, then the workgroup tree)
-static __global__ __launch_bounds__(WG) void k_prob_reduce(const ProbRange* __restrict__ pr, const double* __restrict__ edge_cost,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_prob_reduce(const ProbRange* __restrict__ pr, const double* __restrict__ edge_cost,
                                                     const double* __restrict__ gs, const double* __restrict__ scale,
                                                     const double* __restrict__ x, int lo, ProbSums* __restrict__ out) {
   __shared__ double red[8];
@@ -2647,7 +2669,8 @@ static __global__ __launch_bounds__(WG) void k_prob_reduce(const ProbRange* __re
   }
 }
 // x <- cand on the rows of the accepted problems
-static __global__ void k_accept_rows(int n_loc, int lo, const int32_t* __restrict__ prob_of_256, const int32_t* __restrict__ accept,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_accept_rows(int n_loc, int lo, const int32_t* __restrict__ prob_of_256, const int32_t* __restrict__ accept,
                               const double* __restrict__ cand, double* __restrict__ x) {
   const int64_t n3 = 3 * (int64_t)n_loc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
@@ -2660,7 +2683,8 @@ static __global__ void k_accept_rows(int n_loc, int lo, const int32_t* __restric
 //     y.(H y) = y.b - y.r - y.(D y)
 // -- three dot products over vectors that are there anyway instead of one more SpMV per LM iteration.  Partials of
 // y.b, y.r and y.(D y) per workgroup.
-static __global__ __launch_bounds__(WG) void k_model_terms(int64_t n, const double* __restrict__ y, const double* __restrict__ b,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_model_terms(int64_t n, const double* __restrict__ y, const double* __restrict__ b,
                                                     const double* __restrict__ r, const double* __restrict__ d2,
                                                     double* __restrict__ part_yb, double* __restrict__ part_yr,
                                                     double* __restrict__ part_ydy) {
@@ -2683,7 +2707,8 @@ static __global__ __launch_bounds__(WG) void k_model_terms(int64_t n, const doub
 }
 
 // partials of a.b over n doubles
-static __global__ __launch_bounds__(WG) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
                                             double* __restrict__ part) {
   __shared__ double red[8];
   double s = 0.0;
@@ -2692,10 +2717,12 @@ static __global__ __launch_bounds__(WG) void k_dot(int64_t n, const double* __re
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-static __global__ void k_flag_to_double(const int* __restrict__ flag, double* __restrict__ out) { out[0] = (double)(*flag); }
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_flag_to_double(const int* __restrict__ flag, double* __restrict__ out) { out[0] = (double)(*flag); }
 
 // copy the owned part of a local [n x 3] vector into the padded, globally indexed gather vector
-static __global__ void k_scatter_owned(int n_loc, int lo, const double* __restrict__ src, double* __restrict__ dst) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_scatter_owned(int n_loc, int lo, const double* __restrict__ src, double* __restrict__ dst) {
   const int64_t n3 = 3 * (int64_t)n_loc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / 3;
@@ -2704,14 +2731,16 @@ static __global__ void k_scatter_owned(int n_loc, int lo, const double* __restri
 }
 
 // halo exchange helpers: pack rows of the gather vector into a contiguous buffer / scatter them back
-static __global__ void k_pack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_pack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
                             double* __restrict__ dst) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n_rows; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t k = i / 3;
     dst[i] = src[PS * (int64_t)rows[k] + (i - 3 * k)];
   }
 }
-static __global__ void k_unpack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ void k_unpack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,
                               double* __restrict__ dst) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n_rows; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t k = i / 3;
@@ -2720,7 +2749,8 @@ static __global__ void k_unpack_rows(int64_t n_rows, const int32_t* __restrict__
 }
 
 // candidate = x - S y on the owned rows; partials of |step|^2
-static __global__ __launch_bounds__(WG) void k_candidate(int n_loc, int lo, const double* __restrict__ x,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_candidate(int n_loc, int lo, const double* __restrict__ x,
                                                   const double* __restrict__ scale, const double* __restrict__ y,
                                                   double* __restrict__ cand, double* __restrict__ part_step2) {
   __shared__ double red[8];
@@ -2736,7 +2766,8 @@ static __global__ __launch_bounds__(WG) void k_candidate(int n_loc, int lo, cons
 }
 
 // partials of |x|^2 over the owned free parameters (scale == 0 marks the constant pose)
-static __global__ __launch_bounds__(WG) void k_xnorm(int n_loc, int lo, const double* __restrict__ x,
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(WG) void k_xnorm(int n_loc, int lo, const double* __restrict__ x,
                                               const double* __restrict__ scale, double* __restrict__ part) {
   __shared__ double red[8];
   double s2 = 0.0;

@@ -278,7 +278,8 @@ __device__ __forceinline__ void solo_precond(const SoloArgs& S, const SoloProb& 
   rr_out = solo_sum(rr, red);
 }
 
-static __global__ __launch_bounds__(SOLO_WG) void k_pcg_solo(SoloArgs S) {
+template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
+__global__ __launch_bounds__(SOLO_WG) void k_pcg_solo(SoloArgs S) {
   __shared__ double scr[SOLO_TILES][3][256];                              // 48 KiB: staged block products
   __shared__ double tile_lds[(SOLO_WG / 64) * 64 * (3 * SOLO_CH + 1)];    // 52 KiB: wave-private chain tiles
   __shared__ double red[16];

@@ -237,7 +237,7 @@ int pgo_edge_chi2(pgo_t* h, const double* poses_or_null, double* chi2_out) {
   if (EL > 0) {
     dev::EdgeArgs A = h->edge_args(x, nullptr, 0);
     const int grid = (int)std::min<int64_t>((EL + dev::WG - 1) / dev::WG, 8192);
-    hipLaunchKernelGGL(dev::k_edge_chi2, dim3(grid), dim3(dev::WG), 0, h->stream, A, (const int32_t*)h->e_orig, h->chi2_buf);
+    hipLaunchKernelGGL(dev::k_edge_chi2<>, dim3(grid), dim3(dev::WG), 0, h->stream, A, (const int32_t*)h->e_orig, h->chi2_buf);
     PGOC(h->check_launch("k_edge_chi2"));
   }
   if (h->multi_rank()) {  // every edge is counted on exactly one rank (flags bit1): the sum assembles the vector
@@ -388,7 +388,7 @@ int pgo_debug_normal_eq(pgo_t* h, double* g_out, double* hdiag_out) {
   if (h->comm && h->comm->world > 1) return fail(PGO_ERR_UNSUPPORTED, "world == 1 only");
   HIPC(hipSetDevice(h->device));
   h->lm_active = false;
-  hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(h->g_rows), dim3(dev::WG), 0, h->stream, h->hd, h->S.n_loc, h->S.lo,
+  hipLaunchKernelGGL(dev::k_jacobi_scale<>, dim3(h->g_rows), dim3(dev::WG), 0, h->stream, h->hd, h->S.n_loc, h->S.lo,
                      h->fixed_internal, 0, h->scale, (const uint8_t*)h->fixed_mask);
   PGOC(h->check_launch("k_jacobi_scale"));
   int st = h->linearize(false);
@@ -429,7 +429,7 @@ int pgo_debug_spmv(pgo_t* h, const double* x, double* yout) {
     src = tmp.data();
   }
   HIPC(hipMemcpyAsync(h->y, src, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(dev::k_scatter_owned, dim3(h->g_flat), dim3(dev::WG), 0, h->stream, h->S.n_loc, h->S.lo, h->y, h->p_full);
+  hipLaunchKernelGGL(dev::k_scatter_owned<>, dim3(h->g_flat), dim3(dev::WG), 0, h->stream, h->S.n_loc, h->S.lo, h->y, h->p_full);
   PGOC(h->spmv_enqueue(h->p_full, h->ap, h->part[0], 0, nullptr));
   if (h->perm.empty()) {
     HIPC(hipMemcpyAsync(yout, h->ap, (size_t)3 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -468,14 +468,14 @@ int pgo_debug_precond(pgo_t* h, const double* r_in, double* z_out) {
     GP.nb = h->grp_nb;
     GP.nb_pad = h->grp_pad;
     GP.n_groups = h->n_groups;
-    hipLaunchKernelGGL(dev::k_cg_init_g, dim3(h->g_grp), dim3(dev::WG), 0, h->stream, V, GP, (const double*)h->ap, h->part[0], h->part[1]);
+    hipLaunchKernelGGL(dev::k_cg_init_g<>, dim3(h->g_grp), dim3(dev::WG), 0, h->stream, V, GP, (const double*)h->ap, h->part[0], h->part[1]);
   } else {
-    hipLaunchKernelGGL(dev::k_cg_init, dim3(h->g_vec), dim3(dev::WG), 0, h->stream, V, (const double*)h->ap, h->part[0], h->part[1]);
+    hipLaunchKernelGGL(dev::k_cg_init<>, dim3(h->g_vec), dim3(dev::WG), 0, h->stream, V, (const double*)h->ap, h->part[0], h->part[1]);
   }
   PGOC(h->check_launch("k_cg_init (debug)"));
   if (h->use_coarse) {   // the second level's share of z
     PGOC(h->coarse_solve(h->part[3], nullptr));
-    hipLaunchKernelGGL(dev::k_coarse_prolong, dim3((unsigned)std::min<int64_t>((h->S.n_loc + 255) / 256, 512)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(dev::k_coarse_prolong<>, dim3((unsigned)std::min<int64_t>((h->S.n_loc + 255) / 256, 512)), dim3(256), 0, h->stream,
                        (int)h->S.n_loc, h->co_agg, (const double*)h->co_pb, (const double*)h->co_ec, h->z, (double*)nullptr, (const int32_t*)h->co_ok);
     PGOC(h->check_launch("k_coarse_prolong"));
   }
@@ -591,12 +591,12 @@ int pgo_bench_precond(pgo_t* h, int reps, pgo_kernel_stats* out) {
     GP.nb_pad = h->grp_pad;
     GP.n_groups = h->n_groups;
     PGOC(time_launches(h, reps, [&] {
-      hipLaunchKernelGGL(dev::k_cg_init_g, dim3(h->g_grp), dim3(dev::WG), 0, h->stream, V, GP, (const double*)h->gs, h->part[0], h->part[1]);
+      hipLaunchKernelGGL(dev::k_cg_init_g<>, dim3(h->g_grp), dim3(dev::WG), 0, h->stream, V, GP, (const double*)h->gs, h->part[0], h->part[1]);
     }, &ms));
     out->algorithmic_bytes = (8.0 * 3 * h->grp_nb + 24.0 + 4 * 24.0) * nl;
   } else {
     PGOC(time_launches(h, reps, [&] {
-      hipLaunchKernelGGL(dev::k_cg_init, dim3(h->g_vec), dim3(dev::WG), 0, h->stream, V, (const double*)h->gs, h->part[0], h->part[1]);
+      hipLaunchKernelGGL(dev::k_cg_init<>, dim3(h->g_vec), dim3(dev::WG), 0, h->stream, V, (const double*)h->gs, h->part[0], h->part[1]);
     }, &ms));
     out->algorithmic_bytes = (48.0 + 24.0 + 4 * 24.0) * nl;
   }

@@ -33,7 +33,7 @@ struct pgo_batch {
 
   int reduce(bool with_cost, bool with_grad, const double* x) {
     pgo_handle& H = *U;
-    hipLaunchKernelGGL(dev::k_prob_reduce, dim3(n), dim3(dev::WG), 0, H.stream, (const dev::ProbRange*)d_range,
+    hipLaunchKernelGGL(dev::k_prob_reduce<>, dim3(n), dim3(dev::WG), 0, H.stream, (const dev::ProbRange*)d_range,
                        with_cost ? (const double*)H.edge_cost : (const double*)nullptr,
                        with_grad ? (const double*)H.gs : (const double*)nullptr, (const double*)H.scale, x, H.S.lo, d_sums);
     PGOC(H.check_launch("k_prob_reduce"));
@@ -50,13 +50,13 @@ int pgo_batch::begin() {
   const pgo_options& o = H.opt;
   for (State& z : st) z = State();
   // iteration 0: unit scales -> column norms -> Jacobi scaling (per column, so per problem by construction)
-  hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(H.g_rows), dim3(dev::WG), 0, H.stream, H.hd, H.S.n_loc, H.S.lo, -1, 0, H.scale,
+  hipLaunchKernelGGL(dev::k_jacobi_scale<>, dim3(H.g_rows), dim3(dev::WG), 0, H.stream, H.hd, H.S.n_loc, H.S.lo, -1, 0, H.scale,
                      (const uint8_t*)H.fixed_mask);
   PGOC(H.check_launch("k_jacobi_scale"));
   PGOC(H.eval_enqueue(H.poses, nullptr, 1, true, 0));
   PGOC(H.assemble_enqueue());
   if (o.jacobi_scaling) {
-    hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(H.g_rows), dim3(dev::WG), 0, H.stream, H.hd, H.S.n_loc, H.S.lo, -1, 1, H.scale,
+    hipLaunchKernelGGL(dev::k_jacobi_scale<>, dim3(H.g_rows), dim3(dev::WG), 0, H.stream, H.hd, H.S.n_loc, H.S.lo, -1, 1, H.scale,
                        (const uint8_t*)H.fixed_mask);
     PGOC(H.check_launch("k_jacobi_scale"));
     PGOC(H.assemble_enqueue());
@@ -120,7 +120,7 @@ int pgo_batch::iterate(bool* all_done) {
   A.x = H.poses;
   A.scale = H.scale;
   A.cand = H.cand;
-  hipLaunchKernelGGL(dev::k_pcg_solo, dim3(n), dim3(dev::SOLO_WG), 0, H.stream, A);
+  hipLaunchKernelGGL(dev::k_pcg_solo<>, dim3(n), dim3(dev::SOLO_WG), 0, H.stream, A);
   PGOC(H.check_launch("k_pcg_solo"));
   HIPC(hipMemcpyAsync(h_out.data(), d_out, (size_t)n * sizeof(dev::SoloOut), hipMemcpyDeviceToHost, H.stream));
   // candidate cost of every problem (the rows of idle problems: cand was not written this iteration -- never read below)
@@ -194,7 +194,7 @@ int pgo_batch::iterate(bool* all_done) {
   }
   if (any_accept) {
     HIPC(hipMemcpyAsync(d_accept, h_accept.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, H.stream));
-    hipLaunchKernelGGL(dev::k_accept_rows, dim3(H.g_flat), dim3(dev::WG), 0, H.stream, H.S.n_loc, H.S.lo, (const int32_t*)H.prob_of_256,
+    hipLaunchKernelGGL(dev::k_accept_rows<>, dim3(H.g_flat), dim3(dev::WG), 0, H.stream, H.S.n_loc, H.S.lo, (const int32_t*)H.prob_of_256,
                        (const int32_t*)d_accept, (const double*)H.cand, H.poses);
     PGOC(H.check_launch("k_accept_rows"));
     // re-linearise everything: the problems that did not move reproduce their records and blocks bit for bit

@@ -257,7 +257,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     grp_prep_grid = std::min((n_groups + prep_gpw - 1) / prep_gpw, 65536);
     PGOC(dalloc(&ginv, (int64_t)n_groups * grp_nb * grp_nb));
     if (grp_lds > 48 * 1024)
-      HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_prepare_groups), hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_prepare_groups<>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)grp_lds));
   } else {
     grp_B = 1;
@@ -458,6 +458,24 @@ int pgo_handle::coarse_setup() {
   PGOC(dalloc(&co_ok, 1));
   if (co_Kp <= COARSE_EXPLICIT_RANK) PGOC(dalloc(&co_ainv, (int64_t)co_Kp * co_Kp));
   co_ndot = co_ainv ? (co_Kp + 3) / 4 : (co_Kp + 255) / 256;
+  if (!co_ainv) {   // tiles of the two triangular products
+    const int nb = co_Kp / 32;
+    co_nchunk = (co_Kp + dev::TRI_CW - 1) / dev::TRI_CW;
+    std::vector<int2> ta, tb;
+    for (int b = 0; b < nb; ++b) {
+      for (int j = 0; j * dev::TRI_CW < 32 * (b + 1); ++j) ta.push_back(make_int2(b, j));
+      for (int i = (32 * b) / dev::TRI_CW; i * dev::TRI_CW < 32 * nb; ++i) tb.push_back(make_int2(b, i));
+    }
+    co_nta = (int)ta.size();
+    co_ntb = (int)tb.size();
+    PGOC(dalloc(&co_tiles_a, co_nta));
+    PGOC(dalloc(&co_tiles_b, co_ntb));
+    PGOC(dalloc(&co_part_a, (int64_t)nb * co_nchunk * 32));
+    PGOC(dalloc(&co_part_b, (int64_t)nb * co_nchunk * 32));
+    PGOC(upload(co_tiles_a, ta));
+    PGOC(upload(co_tiles_b, tb));
+    PGOC(sync());   // the lists die with this scope
+  }
   if (g_chain + co_ndot + 8 > part_cap || g_grp + co_ndot + 8 > part_cap || g_vec + co_ndot + 8 > part_cap)
     return no("internal: not enough room for the coarse level's dot partials");
   PGOC(dalloc(&co_cb_i, co_ncb));
@@ -471,7 +489,7 @@ int pgo_handle::coarse_setup() {
   PGOC(upload(co_cb_q, cbq));
   PGOC(upload(co_cb_row, cbr));
   PGOC(sync());   // the host lists die with this scope
-  HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_chol_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::CHOL_LDS_BYTES));
+  HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_chol_panel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::CHOL_LDS_BYTES));
   use_coarse = true;
   if (opt.linear_solver == 0) dl_possible = false;   // (ranks above the direct solve's cheap range: two-level PCG instead of the PCG / direct alternation)
   // the loops that fold launches together assume the one-level preconditioner: two-level solves take the plain three-kernel loop
@@ -588,7 +606,7 @@ int pgo_handle::direct_setup(int32_t N, bool switch_now) {
   }
   PGOC(dalloc(&dl_E, (int64_t)dl_nseg * 3 * dl_ld));
   PGOC(dalloc(&dl_E2, (int64_t)dl_nseg * 3 * dl_ld));
-  HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_chol_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::CHOL_LDS_BYTES));
+  HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(dev::k_chol_panel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev::CHOL_LDS_BYTES));
   PGOC(dalloc(&dl_cvec, dl_Kp));
   PGOC(dalloc(&dl_ksep, 18 * std::max(1, dl_nsep)));
   PGOC(dalloc(&dl_R, std::max(1, dl_nU * dl_nU)));

@@ -34,15 +34,15 @@ int pgo_handle::direct_enqueue() {
   A.sw_c = has_sw ? sw_c : nullptr;
   A.rec_n = rec_doubles;
   A.rec_info = info_mode ? 1 : 0;
-  hipLaunchKernelGGL(dev::k_dlr_setup, dim3((n + dl_m + 255) / 256), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL(dev::k_dlr_setup<>, dim3((n + dl_m + 255) / 256), dim3(256), 0, stream, A);
   PGOC(check_launch("k_dlr_setup"));
-  hipLaunchKernelGGL(dev::k_dlr_factor, dim3(dl_nsep + 1), dim3(64), 0, stream, (const double*)dl_trec, n, dl_fac, A);
+  hipLaunchKernelGGL(dev::k_dlr_factor<>, dim3(dl_nsep + 1), dim3(64), 0, stream, (const double*)dl_trec, n, dl_fac, A);
   PGOC(check_launch("k_dlr_factor"));
-  hipLaunchKernelGGL(dev::k_dlr_prefix, dim3(1), dim3(128), 0, stream, (const double*)dl_fac, n, dl_nseg, dl_seglen, dl_pre);
+  hipLaunchKernelGGL(dev::k_dlr_prefix<>, dim3(1), dim3(128), 0, stream, (const double*)dl_fac, n, dl_nseg, dl_seglen, dl_pre);
   PGOC(check_launch("k_dlr_prefix"));
   const bool one_launch = dl_refine > 0 && dl_pre2 != nullptr;   // the refinement's single column: k_dlr_solve1
   if (one_launch) {
-    hipLaunchKernelGGL(dev::k_dlr_prefix, dim3(1), dim3(512), 0, stream, (const double*)dl_fac, n, dl_nseg2, dl_seglen2, dl_pre2);
+    hipLaunchKernelGGL(dev::k_dlr_prefix<>, dim3(1), dim3(512), 0, stream, (const double*)dl_fac, n, dl_nseg2, dl_seglen2, dl_pre2);
     PGOC(check_launch("k_dlr_prefix (fine segments)"));
   }
   dev::DlrColsArgs C;
@@ -69,9 +69,9 @@ int pgo_handle::direct_enqueue() {
   C.E2 = dl_E2;
   auto solve_columns = [&](const dev::DlrColsArgs& Q) -> int {
     const dim3 grid((Q.ncols + 255) / 256, Q.nseg);
-    hipLaunchKernelGGL(dev::k_dlr_fwd, grid, dim3(256), 0, stream, Q);
-    hipLaunchKernelGGL(dev::k_dlr_mid, grid, dim3(256), 0, stream, Q);
-    hipLaunchKernelGGL(dev::k_dlr_fix, grid, dim3(256), 0, stream, Q);
+    hipLaunchKernelGGL(dev::k_dlr_fwd<>, grid, dim3(256), 0, stream, Q);
+    hipLaunchKernelGGL(dev::k_dlr_mid<>, grid, dim3(256), 0, stream, Q);
+    hipLaunchKernelGGL(dev::k_dlr_fix<>, grid, dim3(256), 0, stream, Q);
     return check_launch("k_dlr_fwd / _mid / _fix");
   };
   PGOC(solve_columns(C));
@@ -93,35 +93,35 @@ int pgo_handle::direct_enqueue() {
     Q.X = X;
     Q.ld = ld;
     Q.ncols = ncols;
-    hipLaunchKernelGGL(dev::k_dlr_sep_w, dim3((ncols + 255) / 256), dim3(256), 0, stream, Q);
-    hipLaunchKernelGGL(dev::k_dlr_sep_apply, dim3((ncols + 255) / 256, (3 * n + 63) / 64), dim3(256), 0, stream, Q);
+    hipLaunchKernelGGL(dev::k_dlr_sep_w<>, dim3((ncols + 255) / 256), dim3(256), 0, stream, Q);
+    hipLaunchKernelGGL(dev::k_dlr_sep_apply<>, dim3((ncols + 255) / 256, (3 * n + 63) / 64), dim3(256), 0, stream, Q);
     return check_launch("k_dlr_sep_w / _apply");
   };
   if (dl_nsep > 0) {
     SA.X = dl_Z;
     SA.ld = dl_ld;
     SA.ncols = K + 1;
-    hipLaunchKernelGGL(dev::k_dlr_sep_system, dim3(1), dim3(256), 0, stream, SA);
+    hipLaunchKernelGGL(dev::k_dlr_sep_system<>, dim3(1), dim3(256), 0, stream, SA);
     PGOC(check_launch("k_dlr_sep_system"));
   }
   PGOC(separator_fix(dl_Z, dl_ld, K + 1));
-  hipLaunchKernelGGL(dev::k_dlr_cap, dim3((std::max(Kp, K + 1) + 255) / 256, Kp), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL(dev::k_dlr_cap<>, dim3((std::max(Kp, K + 1) + 255) / 256, Kp), dim3(256), 0, stream, A);
   PGOC(check_launch("k_dlr_cap"));
   for (int kb = 0; kb < nb; ++kb) {
-    hipLaunchKernelGGL(dev::k_chol_panel, dim3(std::max(1, nb - 1)), dim3(dev::CHOL_THREADS), dev::CHOL_LDS_BYTES, stream, dl_cap, dl_nm, dl_dwork, Kp, nb, kb);
+    hipLaunchKernelGGL(dev::k_chol_panel<>, dim3(std::max(1, nb - 1)), dim3(dev::CHOL_THREADS), dev::CHOL_LDS_BYTES, stream, dl_cap, dl_nm, dl_dwork, Kp, nb, kb);
     PGOC(check_launch("k_chol_panel"));
   }
   auto capacitance_solve = [&]() -> int {  // cvec <- (L L')^-1 cvec = N' (N cvec)
-    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)dl_nm, Kp, nb, (const double*)dl_cvec, dl_cy, 0);
-    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)dl_nm, Kp, nb, (const double*)dl_cy, dl_cvec, 1);
+    hipLaunchKernelGGL(dev::k_tri_apply<>, dim3(nb), dim3(256), 0, stream, (const double*)dl_nm, Kp, nb, (const double*)dl_cvec, dl_cy, 0);
+    hipLaunchKernelGGL(dev::k_tri_apply<>, dim3(nb), dim3(256), 0, stream, (const double*)dl_nm, Kp, nb, (const double*)dl_cy, dl_cvec, 1);
     return check_launch("k_tri_apply");
   };
   PGOC(capacitance_solve());
-  hipLaunchKernelGGL(dev::k_dlr_combine, dim3((3 * n + 3) / 4), dim3(256), 0, stream, (const double*)dl_Z, dl_ld, K, (const double*)dl_cvec,
+  hipLaunchKernelGGL(dev::k_dlr_combine<>, dim3((3 * n + 3) / 4), dim3(256), 0, stream, (const double*)dl_Z, dl_ld, K, (const double*)dl_cvec,
                      (const double*)dl_Z, dl_ld, K, 3 * n, y, 0);
   PGOC(check_launch("k_dlr_combine"));
   auto residual_product = [&]() -> int {  // ap = (H + D'D) y
-    hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
+    hipLaunchKernelGGL(dev::k_scatter_owned<>, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
     PGOC(check_launch("k_scatter_owned"));
     return spmv_enqueue(p_full, ap, part[0], 1, nullptr);
   };
@@ -146,7 +146,7 @@ int pgo_handle::direct_enqueue() {
       Q.Y = dl_Z + (K + 1);
       Q.yld = dl_ld;
       Q.Sinv = dl_R;
-      hipLaunchKernelGGL(dev::k_dlr_solve1, dim3(1), dim3(256), 0, stream, Q);
+      hipLaunchKernelGGL(dev::k_dlr_solve1<>, dim3(1), dim3(256), 0, stream, Q);
       PGOC(check_launch("k_dlr_solve1"));
       xld = 1;
     } else {
@@ -161,18 +161,18 @@ int pgo_handle::direct_enqueue() {
       PGOC(solve_columns(C1));
       PGOC(separator_fix(dl_x1, 64, 1));
     }
-    hipLaunchKernelGGL(dev::k_dlr_vdot, dim3((Kp + 255) / 256), dim3(256), 0, stream, A, (const double*)dl_x1, xld, 0, dl_cvec);
+    hipLaunchKernelGGL(dev::k_dlr_vdot<>, dim3((Kp + 255) / 256), dim3(256), 0, stream, A, (const double*)dl_x1, xld, 0, dl_cvec);
     PGOC(check_launch("k_dlr_vdot"));
     PGOC(capacitance_solve());
-    hipLaunchKernelGGL(dev::k_dlr_combine, dim3((3 * n + 3) / 4), dim3(256), 0, stream, (const double*)dl_Z, dl_ld, K, (const double*)dl_cvec,
+    hipLaunchKernelGGL(dev::k_dlr_combine<>, dim3((3 * n + 3) / 4), dim3(256), 0, stream, (const double*)dl_Z, dl_ld, K, (const double*)dl_cvec,
                        (const double*)dl_x1, xld, 0, 3 * n, y, 1);
     PGOC(check_launch("k_dlr_combine"));
   }
   PGOC(residual_product());
-  hipLaunchKernelGGL(dev::k_dlr_resid, dim3((3 * n + 255) / 256), dim3(256), 0, stream, (int64_t)3 * n, (const double*)gs, (const double*)ap, r);
+  hipLaunchKernelGGL(dev::k_dlr_resid<>, dim3((3 * n + 255) / 256), dim3(256), 0, stream, (int64_t)3 * n, (const double*)gs, (const double*)ap, r);
   PGOC(check_launch("k_dlr_resid"));
-  hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)r, (const double*)r, part[2]);
-  hipLaunchKernelGGL(dev::k_dot, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)gs, (const double*)gs, part[4]);
+  hipLaunchKernelGGL(dev::k_dot<>, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)r, (const double*)r, part[2]);
+  hipLaunchKernelGGL(dev::k_dot<>, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * n, (const double*)gs, (const double*)gs, part[4]);
   PGOC(check_launch("k_dot"));
   return reduce_to_scal({{part[2], g_flat, 0}, {part[4], g_flat, 0}}, 8);
 }

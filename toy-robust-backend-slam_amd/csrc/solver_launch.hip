@@ -15,7 +15,7 @@ int pgo_handle::reduce_to_scal(std::initializer_list<PartRef> parts, int first, 
   }
   F.count = k;
   F.out = scal + first;
-  hipLaunchKernelGGL(dev::k_finalize, dim3(1), dim3(dev::WG), 0, stream, F);
+  hipLaunchKernelGGL(dev::k_finalize<>, dim3(1), dim3(dev::WG), 0, stream, F);
   PGOC(check_launch("k_finalize"));
   if (multi_rank()) PGOC(comm->allreduce(scal + first, k, allreduce_max, stream));
   return PGO_OK;
@@ -26,13 +26,13 @@ int pgo_handle::share_gather_vector(double* full) {
   if (!use_halo) return allgather(full, dev::PS);
   const int64_t ns = (int64_t)S.halo_send_row.size(), nr = (int64_t)S.halo_recv_row.size();
   if (ns > 0) {
-    hipLaunchKernelGGL(dev::k_pack_rows, dim3((unsigned)std::min<int64_t>((3 * ns + 255) / 256, 2048)), dim3(256), 0, stream, ns,
+    hipLaunchKernelGGL(dev::k_pack_rows<>, dim3((unsigned)std::min<int64_t>((3 * ns + 255) / 256, 2048)), dim3(256), 0, stream, ns,
                        (const int32_t*)halo_send_rows, (const double*)full, halo_send_buf);
     PGOC(check_launch("k_pack_rows"));
   }
   PGOC(comm->exchange(halo_send_buf, halo_send_off3.data(), halo_recv_buf, halo_recv_off3.data(), stream));
   if (nr > 0) {
-    hipLaunchKernelGGL(dev::k_unpack_rows, dim3((unsigned)std::min<int64_t>((3 * nr + 255) / 256, 2048)), dim3(256), 0, stream, nr,
+    hipLaunchKernelGGL(dev::k_unpack_rows<>, dim3((unsigned)std::min<int64_t>((3 * nr + 255) / 256, 2048)), dim3(256), 0, stream, nr,
                        (const int32_t*)halo_recv_rows, (const double*)halo_recv_buf, full);
     PGOC(check_launch("k_unpack_rows"));
   }
@@ -55,7 +55,7 @@ int pgo_handle::eval_enqueue(const double* x, const double* sw_vals, int apply_l
   launch_eval(x, sw_vals, apply_loss, with_jac);
   PGOC(check_launch("k_edge_eval"));
   // the flag rides along as a "partial array" of length 1 after conversion to double
-  hipLaunchKernelGGL(dev::k_flag_to_double, dim3(1), dim3(1), 0, stream, bad, part[4]);
+  hipLaunchKernelGGL(dev::k_flag_to_double<>, dim3(1), dim3(1), 0, stream, bad, part[4]);
   return reduce_to_scal({{part[5], g_edge, 0}, {part[4], 1, 0}}, slot);
 }
 
@@ -66,7 +66,7 @@ int pgo_handle::assemble_enqueue() {
   else hipLaunchKernelGGL((dev::k_assemble<false, false>), dim3(g_asm), dim3(dev::WG), 0, stream, asm_args());
   PGOC(check_launch("k_assemble"));
   if (chain_len && n_chain_dup > 0) {
-    hipLaunchKernelGGL(dev::k_chain_dupfix, dim3((n_chain_dup + 63) / 64), dim3(64), 0, stream, (const int32_t*)chain_dup_rows, n_chain_dup,
+    hipLaunchKernelGGL(dev::k_chain_dupfix<>, dim3((n_chain_dup + 63) / 64), dim3(64), 0, stream, (const int32_t*)chain_dup_rows, n_chain_dup,
                        (const int32_t*)inc_ptr, (const int32_t*)inc_col, (const double*)hoff, S.lo, chain_c);
     PGOC(check_launch("k_chain_dupfix"));
   }
@@ -96,7 +96,7 @@ int pgo_handle::spmv_with_halo(double* full, double* yout, double* dot_part, con
   }
   const int64_t ns = (int64_t)S.halo_send_row.size(), nr = (int64_t)S.halo_recv_row.size();
   if (ns > 0) {
-    hipLaunchKernelGGL(dev::k_pack_rows, dim3((unsigned)std::min<int64_t>((3 * ns + 255) / 256, 2048)), dim3(256), 0, stream, ns,
+    hipLaunchKernelGGL(dev::k_pack_rows<>, dim3((unsigned)std::min<int64_t>((3 * ns + 255) / 256, 2048)), dim3(256), 0, stream, ns,
                        (const int32_t*)halo_send_rows, (const double*)full, halo_send_buf);
     PGOC(check_launch("k_pack_rows"));
   }
@@ -111,7 +111,7 @@ int pgo_handle::spmv_with_halo(double* full, double* yout, double* dot_part, con
   HIPC(hipStreamWaitEvent(comm_stream, ev_pack, 0));
   PGOC(comm->exchange(halo_send_buf, halo_send_off3.data(), halo_recv_buf, halo_recv_off3.data(), comm_stream));
   if (nr > 0) {
-    hipLaunchKernelGGL(dev::k_unpack_rows, dim3((unsigned)std::min<int64_t>((3 * nr + 255) / 256, 2048)), dim3(256), 0, comm_stream, nr,
+    hipLaunchKernelGGL(dev::k_unpack_rows<>, dim3((unsigned)std::min<int64_t>((3 * nr + 255) / 256, 2048)), dim3(256), 0, comm_stream, nr,
                        (const int32_t*)halo_recv_rows, (const double*)halo_recv_buf, full);
     PGOC(check_launch("k_unpack_rows"));
   }
@@ -130,7 +130,7 @@ int pgo_handle::spmv_with_halo(double* full, double* yout, double* dot_part, con
     R.n_rows = n_rr;
     R.lo = S.lo;
     R.done = done;
-    hipLaunchKernelGGL(dev::k_spmv_remote, dim3(g_rr), dim3(dev::WG), 0, stream, R);
+    hipLaunchKernelGGL(dev::k_spmv_remote<>, dim3(g_rr), dim3(dev::WG), 0, stream, R);
     PGOC(check_launch("k_spmv_remote"));
     used += g_rr;
   }
@@ -145,7 +145,7 @@ void pgo_handle::launch_cg_init_chain(const double* b, double* part_rz, double* 
   else if (chain_chunk == 2) hipLaunchKernelGGL((dev::k_cg_init_cl<2, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, chain_steps, chain_scan, b, part_rz, part_bb);
   else if (chain_chunk == 4 && chain_nw == 4) hipLaunchKernelGGL((dev::k_cg_init_cl<4, 4>), dim3(g_chain), dim3(256), 0, stream, V, CP, chain_steps, chain_scan, b, part_rz, part_bb);
   else if (chain_chunk == 4) hipLaunchKernelGGL((dev::k_cg_init_cl<4, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, chain_steps, chain_scan, b, part_rz, part_bb);
-  else hipLaunchKernelGGL(dev::k_cg_init_c, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, b, part_rz, part_bb);
+  else hipLaunchKernelGGL(dev::k_cg_init_c<>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, b, part_rz, part_bb);
 }
 
 void pgo_handle::launch_cg_sr_chain(const dev::CgVec& V, double* part_gamma, double* part_rr) {
@@ -162,5 +162,5 @@ void pgo_handle::launch_cg_update1_chain(const dev::CgVec& V, int par, const dou
   else if (chain_chunk == 2) hipLaunchKernelGGL((dev::k_cg_update1_cl<2, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, chain_steps, chain_scan, par, pap, n_pap, part_rz, part_rr);
   else if (chain_chunk == 4 && chain_nw == 4) hipLaunchKernelGGL((dev::k_cg_update1_cl<4, 4>), dim3(g_chain), dim3(256), 0, stream, V, CP, chain_steps, chain_scan, par, pap, n_pap, part_rz, part_rr);
   else if (chain_chunk == 4) hipLaunchKernelGGL((dev::k_cg_update1_cl<4, 1>), dim3(g_chain), dim3(64), 0, stream, V, CP, chain_steps, chain_scan, par, pap, n_pap, part_rz, part_rr);
-  else hipLaunchKernelGGL(dev::k_cg_update1_c, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, par, pap, n_pap, part_rz, part_rr);
+  else hipLaunchKernelGGL(dev::k_cg_update1_c<>, dim3(g_chain), dim3(dev::WG), 0, stream, V, CP, par, pap, n_pap, part_rz, part_rr);
 }

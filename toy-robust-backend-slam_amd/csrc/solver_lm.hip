@@ -25,11 +25,11 @@ int pgo_handle::linearize(bool reuse_records, bool assemble) {
 // the current radius, re-assembly of the reduced pose system, gradient max-norm over poses AND switches, sum s^2.
 int pgo_handle::refresh_switch_system() {
   const int g_sw = std::min(std::max(1, (S.n_edges_local + dev::WG - 1) / dev::WG), 1024);
-  hipLaunchKernelGGL(dev::k_switch_prepare, dim3(g_sw), dim3(dev::WG), 0, stream, switch_arrays(), (const double*)jr, radius,
+  hipLaunchKernelGGL(dev::k_switch_prepare<>, dim3(g_sw), dim3(dev::WG), 0, stream, switch_arrays(), (const double*)jr, radius,
                      opt.min_lm_diagonal, opt.max_lm_diagonal, part[2], part[3]);
   PGOC(check_launch("k_switch_prepare"));
   PGOC(assemble_enqueue());
-  hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, (const double*)gs_full, (const double*)scale, S.n_loc,
+  hipLaunchKernelGGL(dev::k_grad_max<>, dim3(g_flat), dim3(dev::WG), 0, stream, (const double*)gs_full, (const double*)scale, S.n_loc,
                      S.lo, part[0]);
   PGOC(check_launch("k_grad_max"));
   PGOC(reduce_to_scal({{part[0], g_flat, 1}, {part[2], g_sw, 1}}, 10, true));
@@ -73,27 +73,27 @@ int pgo_handle::lm_begin() {
     PGOC(sync());  // `ones` dies with this scope
   }
   // pass 1: unit scales (0 on the constant pose) -> column norms for Jacobi scaling
-  hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 0, scale, (const uint8_t*)fixed_mask);
+  hipLaunchKernelGGL(dev::k_jacobi_scale<>, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 0, scale, (const uint8_t*)fixed_mask);
   PGOC(check_launch("k_jacobi_scale"));
   PGOC(allgather(scale));
   PGOC(linearize(false));
   const double cost0 = h_scal[0];
   if (has_sw) {  // Jacobi scale of the switch columns from the iteration-0 Jacobian
-    hipLaunchKernelGGL(dev::k_switch_scale, dim3((S.n_edges_local + 255) / 256 + 1), dim3(256), 0, stream, switch_arrays(),
+    hipLaunchKernelGGL(dev::k_switch_scale<>, dim3((S.n_edges_local + 255) / 256 + 1), dim3(256), 0, stream, switch_arrays(),
                        opt.jacobi_scaling);
     PGOC(check_launch("k_switch_scale"));
   }
   if (opt.jacobi_scaling) {
-    hipLaunchKernelGGL(dev::k_jacobi_scale, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 1, scale, (const uint8_t*)fixed_mask);
+    hipLaunchKernelGGL(dev::k_jacobi_scale<>, dim3(g_rows), dim3(dev::WG), 0, stream, hd, S.n_loc, S.lo, fixed, 1, scale, (const uint8_t*)fixed_mask);
     PGOC(check_launch("k_jacobi_scale"));
     PGOC(allgather(scale));
     PGOC(linearize(true));  // the records do not depend on the scales: re-assemble only
   }
   cost = initial_cost = cost0;
-  hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
+  hipLaunchKernelGGL(dev::k_grad_max<>, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
   PGOC(check_launch("k_grad_max"));
   PGOC(reduce_to_scal({{part[0], g_flat, 1}}, 2, true));
-  hipLaunchKernelGGL(dev::k_xnorm, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, poses, scale, part[1]);
+  hipLaunchKernelGGL(dev::k_xnorm<>, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, poses, scale, part[1]);
   PGOC(check_launch("k_xnorm"));
   PGOC(reduce_to_scal({{part[1], g_flat, 0}}, 3));
   PGOC(fetch_scal(2, 2));
@@ -226,29 +226,29 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
     // (rtol 0.1, ~100 iterations) keeps the recurrence residual; the direct solve writes the true residual itself.
     const bool true_residual = k_it > 0 && (opt.pcg_rtol < 1e-6 || k_it > 1000);
     if (has_sw || true_residual) {  // (the switch back-substitution below reads y of both endpoints from the gather vector)
-      hipLaunchKernelGGL(dev::k_scatter_owned, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
+      hipLaunchKernelGGL(dev::k_scatter_owned<>, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, y, p_full);
       PGOC(check_launch("k_scatter_owned"));
       PGOC(share_gather_vector(p_full));
     }
     if (true_residual) {
       PGOC(spmv_enqueue(p_full, ap, part[0], 1, nullptr));
-      hipLaunchKernelGGL(dev::k_dlr_resid, dim3((3 * S.n_loc + 255) / 256), dim3(256), 0, stream, (int64_t)3 * S.n_loc, (const double*)gs,
+      hipLaunchKernelGGL(dev::k_dlr_resid<>, dim3((3 * S.n_loc + 255) / 256), dim3(256), 0, stream, (int64_t)3 * S.n_loc, (const double*)gs,
                          (const double*)ap, r);
       PGOC(check_launch("k_dlr_resid"));
     }
     // y.(H y) = y.b - y.r - y.(D y) from the residual (no further product by H): part[1] = y.b, part[0] = y.r, part[5] = y.(D y)
-    hipLaunchKernelGGL(dev::k_model_terms, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs,
+    hipLaunchKernelGGL(dev::k_model_terms<>, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)y, (const double*)gs,
                        (const double*)r, (const double*)d2, part[1], part[0], part[5]);
     PGOC(check_launch("k_model_terms"));
     // candidate x + d and |d|^2
     double* x_old = poses;
-    hipLaunchKernelGGL(dev::k_candidate, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, x_old, scale, y, cand, part[3]);
+    hipLaunchKernelGGL(dev::k_candidate<>, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, x_old, scale, y, cand, part[3]);
     PGOC(check_launch("k_candidate"));
   }
   double model_sw = 0.0, step2_sw = 0.0;
   if (has_sw) {  // back-substitute the switches (needs y of both endpoints: in the gather vector after the share above)
     const int g_sw = std::min(std::max(1, (S.n_edges_local + dev::WG - 1) / dev::WG), 1024);
-    hipLaunchKernelGGL(dev::k_switch_backsub, dim3(g_sw), dim3(dev::WG), 0, stream, switch_arrays(), (const int32_t*)e_ia,
+    hipLaunchKernelGGL(dev::k_switch_backsub<>, dim3(g_sw), dim3(dev::WG), 0, stream, switch_arrays(), (const int32_t*)e_ia,
                        (const int32_t*)e_ib, (const double*)jr, (const double*)scale, (const double*)p_full, part[2], part[4]);
     PGOC(check_launch("k_switch_backsub"));
     PGOC(reduce_to_scal({{part[2], g_sw, 0}, {part[4], g_sw, 0}}, 13));
@@ -342,7 +342,7 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
   if (rho > opt.min_relative_decrease) {  // HandleSuccessfulStep
     std::swap(poses, cand);
     if (has_sw) std::swap(sw, sw_cand);
-    hipLaunchKernelGGL(dev::k_xnorm, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, poses, scale, part[1]);
+    hipLaunchKernelGGL(dev::k_xnorm<>, dim3(g_flat), dim3(dev::WG), 0, stream, S.n_loc, S.lo, poses, scale, part[1]);
     PGOC(check_launch("k_xnorm"));
     PGOC(reduce_to_scal({{part[1], g_flat, 0}}, 3));
     const double t = 2.0 * rho - 1.0;
@@ -366,7 +366,7 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
       const double tl0 = wall_s();
       PGOC(eval_enqueue(poses, sw, 1, true, 0));
       PGOC(assemble_enqueue());
-      hipLaunchKernelGGL(dev::k_grad_max, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
+      hipLaunchKernelGGL(dev::k_grad_max<>, dim3(g_flat), dim3(dev::WG), 0, stream, gs, scale, S.n_loc, S.lo, part[0]);
       PGOC(check_launch("k_grad_max"));
       PGOC(reduce_to_scal({{part[0], g_flat, 1}}, 2, true));
       PGOC(fetch_scal(0, 4));

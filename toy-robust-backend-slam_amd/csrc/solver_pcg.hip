@@ -25,46 +25,48 @@ int pgo_handle::coarse_factor() {
   A.n_cb = co_ncb;
   A.cap = co_cap;
   A.dwork = co_dwork;
-  hipLaunchKernelGGL(dev::k_coarse_basis, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL(dev::k_coarse_basis<>, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, A);
   PGOC(check_launch("k_coarse_basis"));
   HIPC(hipMemsetAsync(co_cap, 0, (size_t)co_Kp * co_Kp * sizeof(double), stream));
   HIPC(hipMemsetAsync(co_dwork, 0, (size_t)(co_Kp / 32) * 1024 * sizeof(double), stream));
-  hipLaunchKernelGGL(dev::k_coarse_assemble, dim3((co_ncb + 3) / 4), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL(dev::k_coarse_assemble<>, dim3((co_ncb + 3) / 4), dim3(256), 0, stream, A);
   PGOC(check_launch("k_coarse_assemble"));
   if (co_Kp > co_K) {
-    hipLaunchKernelGGL(dev::k_coarse_pad, dim3(1), dim3(32), 0, stream, co_cap, co_dwork, co_K, co_Kp);
+    hipLaunchKernelGGL(dev::k_coarse_pad<>, dim3(1), dim3(32), 0, stream, co_cap, co_dwork, co_K, co_Kp);
     PGOC(check_launch("k_coarse_pad"));
   }
   const int nb = co_Kp / 32;
   for (int kb = 0; kb < nb; ++kb) {
-    hipLaunchKernelGGL(dev::k_chol_panel, dim3(std::max(1, nb - 1)), dim3(dev::CHOL_THREADS), dev::CHOL_LDS_BYTES, stream, co_cap, co_nm, co_dwork, co_Kp, nb, kb);
+    hipLaunchKernelGGL(dev::k_chol_panel<>, dim3(std::max(1, nb - 1)), dim3(dev::CHOL_THREADS), dev::CHOL_LDS_BYTES, stream, co_cap, co_nm, co_dwork, co_Kp, nb, kb);
     PGOC(check_launch("k_chol_panel (coarse level)"));
   }
   // usable?  a probe through the factor: x = A_c^-1 1 must be finite (a pivot lost to rounding leaves NaNs behind it)
-  hipLaunchKernelGGL(dev::k_fill, dim3((co_Kp + 255) / 256), dim3(256), 0, stream, co_rc, (int64_t)co_Kp, 1.0);
+  hipLaunchKernelGGL(dev::k_fill<>, dim3((co_Kp + 255) / 256), dim3(256), 0, stream, co_rc, (int64_t)co_Kp, 1.0);
   if (co_ainv) {
-    hipLaunchKernelGGL(dev::k_coarse_ainv, dim3((co_Kp + 255) / 256, co_Kp), dim3(256), 0, stream, (const double*)co_nm, co_Kp, co_ainv);
-    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_ainv, co_Kp, nb, (const double*)co_rc, co_ec, 0);
+    hipLaunchKernelGGL(dev::k_coarse_ainv<>, dim3((co_Kp + 255) / 256, co_Kp), dim3(256), 0, stream, (const double*)co_nm, co_Kp, co_ainv);
+    hipLaunchKernelGGL(dev::k_tri_apply<>, dim3(nb), dim3(256), 0, stream, (const double*)co_ainv, co_Kp, nb, (const double*)co_rc, co_ec, 0);
   } else {
-    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_rc, co_cy, 0);
-    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_cy, co_ec, 1);
+    hipLaunchKernelGGL(dev::k_tri_apply<>, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_rc, co_cy, 0);
+    hipLaunchKernelGGL(dev::k_tri_apply<>, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_cy, co_ec, 1);
   }
-  hipLaunchKernelGGL(dev::k_coarse_check, dim3(1), dim3(256), 0, stream, (const double*)co_ec, co_Kp, co_ok);
+  hipLaunchKernelGGL(dev::k_coarse_check<>, dim3(1), dim3(256), 0, stream, (const double*)co_ec, co_Kp, co_ok);
   return check_launch("coarse level probe");
 }
 
 int pgo_handle::coarse_solve(double* dot_part, const int32_t* done) {
   const int nb = co_Kp / 32;
-  hipLaunchKernelGGL(dev::k_coarse_restrict, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, (int)S.n_loc, co_agg, co_nagg, (const double*)co_pb,
+  hipLaunchKernelGGL(dev::k_coarse_restrict<>, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, (int)S.n_loc, co_agg, co_nagg, (const double*)co_pb,
                      (const double*)r, co_rc, done);
   if (co_ainv) {
-    hipLaunchKernelGGL(dev::k_coarse_matvec, dim3(co_ndot), dim3(256), 0, stream, (const double*)co_ainv, co_Kp, (const double*)co_rc, co_ec,
+    hipLaunchKernelGGL(dev::k_coarse_matvec<>, dim3(co_ndot), dim3(256), 0, stream, (const double*)co_ainv, co_Kp, (const double*)co_rc, co_ec,
                        dot_part, (const int32_t*)co_ok, done);
   } else {
-    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_rc, co_cy, 0);
-    hipLaunchKernelGGL(dev::k_tri_apply, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_cy, co_ec, 1);
-    hipLaunchKernelGGL(dev::k_coarse_dot, dim3(co_ndot), dim3(256), 0, stream, co_Kp, (const double*)co_rc, co_ec, dot_part,
-                       (const int32_t*)co_ok, done);
+    hipLaunchKernelGGL(dev::k_tri_tiles_a<>, dim3(co_nta), dim3(256), 0, stream, (const double*)co_nm, co_Kp, (const int2*)co_tiles_a,
+                       (const double*)co_rc, co_part_a, co_nchunk, done);
+    hipLaunchKernelGGL(dev::k_tri_tiles_b<>, dim3(co_ntb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const int2*)co_tiles_b,
+                       (const double*)co_part_a, co_part_b, co_nchunk, done);
+    hipLaunchKernelGGL(dev::k_tri_finish<>, dim3(co_ndot), dim3(256), 0, stream, co_Kp, nb, co_nchunk, (const double*)co_part_b,
+                       (const double*)co_rc, co_ec, dot_part, (const int32_t*)co_ok, done);
   }
   return check_launch("coarse level solve");
 }
@@ -95,7 +97,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
     A.x = poses;
     A.scale = scale;
     A.cand = cand;
-    hipLaunchKernelGGL(dev::k_pcg_solo, dim3(1), dim3(dev::SOLO_WG), 0, stream, A);
+    hipLaunchKernelGGL(dev::k_pcg_solo<>, dim3(1), dim3(dev::SOLO_WG), 0, stream, A);
     PGOC(check_launch("k_pcg_solo"));
     HIPC(hipMemcpyAsync(h_solo, solo_out, sizeof(dev::SoloOut), hipMemcpyDeviceToHost, stream));
     PGOC(sync());  // P (stack) was consumed by the copy above
@@ -115,8 +117,8 @@ int pgo_handle::pcg(int* iters, double* rel) {
   const bool grouped = grp_B > 1, chained = chain_len > 0;
   const int g_u1 = chained ? g_chain : (grouped ? g_grp : g_vec);  // grid (= number of partials) of the init / update1 kernels
   if (chained) launch_cg_init_chain(gs, part[0], part[1]);
-  else if (grouped) hipLaunchKernelGGL(dev::k_cg_init_g, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, (const double*)gs, part[0], part[1]);
-  else hipLaunchKernelGGL(dev::k_cg_init, dim3(g_u1), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
+  else if (grouped) hipLaunchKernelGGL(dev::k_cg_init_g<>, dim3(g_u1), dim3(dev::WG), 0, stream, V, GP, (const double*)gs, part[0], part[1]);
+  else hipLaunchKernelGGL(dev::k_cg_init<>, dim3(g_u1), dim3(dev::WG), 0, stream, V, gs, part[0], part[1]);
   PGOC(check_launch("k_cg_init"));
   const bool sr = use_sr && chained;
   // single-reduction loop: "make u visible to the peers, w = A u, reduce (gamma, rr, delta) together, new coefficients"
@@ -129,7 +131,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
       PGOC(spmv_enqueue(p_full, ap, part[2], 1, done));
     }
     PGOC(reduce_to_scal({{part[0], g_u1, 0}, {part[1], g_u1, 0}, {part[2], n_sp, 0}}, 4));
-    hipLaunchKernelGGL(dev::k_cg_sr_scal, dim3(1), dim3(1), 0, stream, st, (const double*)(scal + 4), opt.pcg_rtol, first);
+    hipLaunchKernelGGL(dev::k_cg_sr_scal<>, dim3(1), dim3(1), 0, stream, st, (const double*)(scal + 4), opt.pcg_rtol, first);
     return check_launch("k_cg_sr_scal");
   };
   if (sr) {
@@ -141,12 +143,12 @@ int pgo_handle::pcg(int* iters, double* rel) {
     const int n_rz0 = use_coarse ? g_u1 + co_ndot : g_u1;
     if (use_coarse) {
       PGOC(coarse_solve(part[0] + g_u1, nullptr));
-      hipLaunchKernelGGL(dev::k_coarse_prolong, dim3((unsigned)std::min<int64_t>((S.n_loc + 255) / 256, 512)), dim3(256), 0, stream, (int)S.n_loc,
+      hipLaunchKernelGGL(dev::k_coarse_prolong<>, dim3((unsigned)std::min<int64_t>((S.n_loc + 255) / 256, 512)), dim3(256), 0, stream, (int)S.n_loc,
                          co_agg, (const double*)co_pb, (const double*)co_ec, z, p_full + dev::PS * (int64_t)S.lo, (const int32_t*)co_ok);
       PGOC(check_launch("k_coarse_prolong"));
     }
     PGOC(reduce_to_scal({{part[0], n_rz0, 0}, {part[1], g_u1, 0}}, 4));
-    hipLaunchKernelGGL(dev::k_cg_init_fin, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
+    hipLaunchKernelGGL(dev::k_cg_init_fin<>, dim3(1), dim3(1), 0, stream, st, scal + 4, opt.pcg_rtol);
     PGOC(check_launch("k_cg_init_fin"));
     if (!overlap) PGOC(share_gather_vector(p_full));
   }
@@ -184,23 +186,23 @@ int pgo_handle::pcg(int* iters, double* rel) {
     const int n_pap = multi ? 1 : n_sp;
     if (multi) PGOC(reduce_to_scal({{part[0], n_sp, 0}}, 6));
     if (chained) launch_cg_update1_chain(Vi, par, pap, n_pap, part[1], part[2]);
-    else if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, GP, par, pap, n_pap, part[1], part[2]);
-    else hipLaunchKernelGGL(dev::k_cg_update1, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, par, pap, n_pap, part[1], part[2]);
+    else if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g<>, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, GP, par, pap, n_pap, part[1], part[2]);
+    else hipLaunchKernelGGL(dev::k_cg_update1<>, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, par, pap, n_pap, part[1], part[2]);
     PGOC(check_launch("k_cg_update1"));
     if (fused) return PGO_OK;  // its r.z / r.r partials are booked by the next SpMV, or by k_cg_book at the end of the slice
     if (use_coarse) {   // second level (single rank): e_c, its share of r.z as more partials, prolongation inside the direction update
       PGOC(coarse_solve(part[1] + g_u1, &st->done));
-      hipLaunchKernelGGL(dev::k_cg_update2c, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, (const double*)part[1], g_u1 + co_ndot,
+      hipLaunchKernelGGL(dev::k_cg_update2c<>, dim3(g_vec), dim3(dev::WG), 0, stream, V, par, (const double*)part[1], g_u1 + co_ndot,
                          (const double*)part[2], g_u1, co_agg, (const double*)co_pb, (const double*)co_ec);
       return check_launch("k_cg_update2c");
     }
     if (multi) {
       PGOC(reduce_to_scal({{part[1], g_u1, 0}, {part[2], g_u1, 0}}, 7));
-      hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
+      hipLaunchKernelGGL(dev::k_cg_update2<>, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, scal + 7, 1, scal + 8, 1);
       PGOC(check_launch("k_cg_update2"));
       if (!overlap) PGOC(share_gather_vector(p_full));
     } else {
-      hipLaunchKernelGGL(dev::k_cg_update2, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_u1, part[2], g_u1);
+      hipLaunchKernelGGL(dev::k_cg_update2<>, dim3(g_flat), dim3(dev::WG), 0, stream, V, par, part[1], g_u1, part[2], g_u1);
       PGOC(check_launch("k_cg_update2"));
     }
     return PGO_OK;
@@ -228,7 +230,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
       int st_cap = PGO_OK;
       for (int c = 0; c < every && st_cap == PGO_OK; ++c) st_cap = enqueue_iteration(c & 1);
       if (fused && st_cap == PGO_OK) {
-        hipLaunchKernelGGL(dev::k_cg_book, dim3(1), dim3(dev::WG), 0, stream, st, (every - 1) & 1, (const double*)part[1], g_u1, (const double*)part[2], g_u1);
+        hipLaunchKernelGGL(dev::k_cg_book<>, dim3(1), dim3(dev::WG), 0, stream, st, (every - 1) & 1, (const double*)part[1], g_u1, (const double*)part[2], g_u1);
         st_cap = check_launch("k_cg_book");
       }
       hipError_t e_end = hipStreamEndCapture(stream, &gr);
@@ -271,7 +273,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
       } else {
         for (int c = 0; c < chunk; ++c) PGOC(enqueue_iteration((it + c) & 1));
         if (fused && chunk > 0) {
-          hipLaunchKernelGGL(dev::k_cg_book, dim3(1), dim3(dev::WG), 0, stream, st, (it + chunk - 1) & 1, (const double*)part[1], g_u1, (const double*)part[2], g_u1);
+          hipLaunchKernelGGL(dev::k_cg_book<>, dim3(1), dim3(dev::WG), 0, stream, st, (it + chunk - 1) & 1, (const double*)part[1], g_u1, (const double*)part[2], g_u1);
           PGOC(check_launch("k_cg_book"));
         }
       }
@@ -305,7 +307,7 @@ int pgo_handle::prepare_preconditioner() {
     GA.B = grp_B;
     GA.nb = grp_nb;
     GA.n_groups = n_groups;
-    hipLaunchKernelGGL(dev::k_prepare_groups, dim3(grp_prep_grid), dim3(dev::WG), grp_lds, stream, GA);
+    hipLaunchKernelGGL(dev::k_prepare_groups<>, dim3(grp_prep_grid), dim3(dev::WG), grp_lds, stream, GA);
     PGOC(check_launch("k_prepare_groups"));
   }
   if (chain_len) PGOC(factor_chain());
@@ -333,7 +335,7 @@ int pgo_handle::factor_chain() {
 
 // LM diagonal for the current radius (per problem in a batched handle) + the preconditioner's set-up
 int pgo_handle::prepare_system() {
-  hipLaunchKernelGGL(dev::k_prepare, dim3(g_rows), dim3(dev::WG), 0, stream, hd, (const double*)diag_full, S.n_loc, S.lo, fixed_internal, radius,
+  hipLaunchKernelGGL(dev::k_prepare<>, dim3(g_rows), dim3(dev::WG), 0, stream, hd, (const double*)diag_full, S.n_loc, S.lo, fixed_internal, radius,
                      opt.min_lm_diagonal, opt.max_lm_diagonal, d2, minv, (const uint8_t*)fixed_mask, (const int32_t*)prob_of_256,
                      (const double*)prob_radius, chain_len ? chain_c : (double*)nullptr, hdd);
   PGOC(check_launch("k_prepare"));
