@@ -50,6 +50,8 @@ int pgo_handle::coarse_factor() {
     hipLaunchKernelGGL(dev::k_tri_apply<>, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_cy, co_ec, 1);
   }
   hipLaunchKernelGGL(dev::k_coarse_check<>, dim3(1), dim3(256), 0, stream, (const double*)co_ec, co_Kp, co_ok);
+  // (the restriction writes the K coarse unknowns only: the padding entries K .. Kp-1 of r_c must read 0 again)
+  hipLaunchKernelGGL(dev::k_fill<>, dim3((co_Kp + 255) / 256), dim3(256), 0, stream, co_rc, (int64_t)co_Kp, 0.0);
   return check_launch("coarse level probe");
 }
 
