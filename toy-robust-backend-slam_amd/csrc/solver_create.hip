@@ -393,12 +393,19 @@ int pgo_handle::coarse_setup() {
   if (batch_mode) return no("not inside a batched handle");
   if (NL < 2) return PGO_OK;
   if (want < 0) {
-    // auto: the exact mode of graphs that stay on PCG (the direct solve, where it applies cheaply, is faster still).
-    // Aggregates of 16 poses up to ~10k poses (M3500: rank 657), growing so that the coarse matrix stays below rank ~2400
-    // (its Cholesky is paid once per LM iteration, its two dense products once per PCG iteration)
-    if (!(opt.pcg_rtol <= 1e-4) || direct || NL < 512) return PGO_OK;
-    want = 16;
-    while (3 * ((NL + want - 1) / want) > 2400) want *= 2;
+    // auto (measured on MI355X, scripts/exp_coarse.py, GN it/s one level -> two levels):
+    //   tight solves (pcg_rtol <= 1e-3) of graphs that stay on PCG -- M3500 METHOD 1 47 -> 156 (16-pose aggregates, coarse
+    //   order 657; 32: 128, 64: 100), FRH 35 -> 199 (16), synthetic 10k at 1e-10 108 -> 137 (64; 16: 127), 100k at 1e-10
+    //   3.7 -> 12.3 and at 1e-3 14.9 -> 40.5 (64, order 4689; 128 and more: no gain) -- 16 poses up to 8192 poses, else
+    //   64, doubled until the coarse order fits the dense factorisation;
+    //   loose solves (the inexact mode) only where the coarse matrix is cheap next to the fine level: 8193 .. 32768 poses
+    //   (10k at rtol 0.1: 371 -> 771 with 64-pose aggregates; 100k: 189 -> 80 .. 121, the factorisation of an order-4689
+    //   matrix per LM iteration costs more than the PCG iterations it saves).
+    if (direct || NL < 512) return PGO_OK;
+    const bool tight = opt.pcg_rtol <= 1e-3;
+    if (!tight && !(NL > 8192 && NL <= 32768)) return PGO_OK;
+    want = NL <= 8192 ? 16 : 64;
+    while (3 * ((NL + want - 1) / want) + 1 > COARSE_MAX_RANK) want *= 2;
   }
   co_agg = want;
   co_nagg = (int)((NL + co_agg - 1) / co_agg);
