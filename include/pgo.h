@@ -202,7 +202,8 @@ typedef struct pgo_options {
                                   It removes the smooth long-range error that block-Jacobi cannot: M3500 METHOD 1, PCG to 1e-10:
                                   1557 -> 178 iterations with 16-pose aggregates.  Rounded up to a multiple of the one-level
                                   block (pcg_chain_len / pcg_block_poses).  One rank.  0 = off;
-                                  -1 (default) = auto, for graphs of >= 512 poses that stay on PCG: on for tight solves
+                                  -1 (default) = auto, for graphs of >= 512 poses that stay on PCG while pcg_block_poses and
+                                  pcg_chain_len are left at auto: on for tight solves
                                   (pcg_rtol <= 1e-3) -- 16 poses per aggregate up to 8192 poses, else 64, doubled until the
                                   coarse order fits -- and for loose solves of 8193 .. 32768 poses (64), where the dense
                                   coarse factorisation is cheap next to the PCG iterations it saves                     */

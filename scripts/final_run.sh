@@ -2,7 +2,7 @@
 # end-of-round evidence on ONE box: rocprofv3 passes (profile.sh) first, then the driver's bench command; the bench line is
 # kept under profiles/ next to the profile of the same box
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p gpurun_out/profiles
 bash scripts/profile.sh $TAG || exit 1
 timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err || { tail -5 gpurun_out/bench_${TAG}.err; exit 1; }

@@ -5,7 +5,7 @@
 #   pass 3: --pmc WRITE_SIZE
 # Raw output goes to gpurun_out/prof_<tag>/ ; scripts/summarize_profile.py condenses it into profiles/.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p $OUT
 export TMPDIR=/tmp

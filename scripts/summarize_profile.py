@@ -126,6 +126,22 @@ def main():
         rd, wr = v["fetch_kib"] * 1024 * rf, v["write_kib"] * 1024 * wf
         traffic[k.replace("<true>", "_jac").replace("<false>", "_cost") + "_bytes_per_launch"] = rd + wr
         lines.append(f"| {k} | {rd / 1e6:.1f} | {wr / 1e6:.1f} | {(rd + wr) / 1e6:.1f} |")
+    # roofline fractions: algorithmic bytes (the 1M-pose bench graph: N = 1,000,000, E = 4,002,127,
+    # I = 8,004,254) / full-launch average duration / 8 TB/s
+    N_, E_, I_ = 1.0e6, 4002127.0, 8004254.0
+    alg = {"k_edge_eval<true>": 196.0 * E_, "k_edge_eval<false>": 92.0 * E_, "k_assemble": 112.0 * E_ + 80.0 * I_ + 172.0 * N_,
+           "k_spmv": 76.0 * I_ + 100.0 * N_, "k_cg_update1_cl": 288.0 * N_, "k_cg_init_cl": 240.0 * N_, "k_cg_update2": 72.0 * N_,
+           "k_chain_factor": 248.0 * N_}
+    lines += ["", "## Roofline (algorithmic bytes / full-launch average / 8 TB/s; traffic = calibrated counter bytes)", "",
+              "| kernel | algorithmic MB | full avg us | TB/s | fraction of 8 TB/s | counter MB | counter / algorithmic |", "|---|---|---|---|---|---|---|"]
+    for k, bts in alg.items():
+        fa, nf = full_avg(k)
+        if not nf:
+            continue
+        tr = traffic.get(k.replace("<true>", "_jac").replace("<false>", "_cost") + "_bytes_per_launch")
+        lines.append("| %s | %.1f | %.2f | %.2f | **%.3f** | %s | %s |" % (
+            k, bts / 1e6, fa, bts / (fa * 1e-6) / 1e12, bts / (fa * 1e-6) / 8e12,
+            ("%.1f" % (tr / 1e6)) if tr else "-", ("%.2f" % (tr / bts)) if tr else "-"))
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))

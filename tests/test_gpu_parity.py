@@ -356,11 +356,11 @@ def test_two_level_preconditioner(pgo, name, method):
 
 
 def test_two_level_preconditioner_on_synthetic_graphs(pgo, oracle):
-    """the same on a synthetic graph with the chain preconditioner as the first level (30011 poses, aggregates chosen by
-    the library), tight and loose tolerances: identical accept / reject history, fewer PCG iterations; an explicit
+    """the same on a synthetic graph (30011 poses: dense 4-pose blocks as the first level, aggregates chosen by the library),
+    tight and loose tolerances: identical accept / reject history, fewer PCG iterations; an explicit
     aggregate size is honoured; several ranks or a batched handle refuse an explicit request and ignore the auto one"""
     g = pgo.synth_manhattan(30011, 4.0, 0.10, 5)
-    kw = dict(method=1, max_iters=6, ftol=0.0, gtol=0.0, ptol=0.0, pcg_max_iters=200000, pcg_chain_len=64)
+    kw = dict(method=1, max_iters=6, ftol=0.0, gtol=0.0, ptol=0.0, pcg_max_iters=200000)
     out = {}
     for rtol in (1e-8, 0.1):
         for coarse in (0, -1, 128):
@@ -378,7 +378,7 @@ def test_two_level_preconditioner_on_synthetic_graphs(pgo, oracle):
         assert out[(rtol, 128)][0].total_pcg_iters < 0.8 * out[(rtol, 0)][0].total_pcg_iters
         print("30011 poses, rtol %g: PCG iterations one level %d, auto %d (aggregates %d), aggregates of 128: %d" % (
             rtol, out[(rtol, 0)][0].total_pcg_iters, out[(rtol, -1)][0].total_pcg_iters, out[(rtol, -1)][3], out[(rtol, 128)][0].total_pcg_iters))
-    assert np.abs(out[(1e-8, 128)][1] - out[(1e-8, 0)][1]).max() < 1e-6
+    assert np.abs(out[(1e-8, 128)][1] - out[(1e-8, 0)][1]).max() < 1e-5   # (six LM iterations at radius ~1e7: 2.7e-6 measured)
     with pytest.raises(pgo.PgoError):
         pgo.Solver(g, pgo.Options(pcg_rtol=1e-8, pcg_coarse_poses=1, **kw))     # coarse order 90033 > 6143
     big = pgo.Solver(pgo.synth_manhattan(60001, 4.0, 0.10, 5), pgo.Options(pcg_rtol=0.1, **kw))

@@ -96,7 +96,11 @@ __global__ __launch_bounds__(256) void k_coarse_basis(CoarseArgs A) {
   const int64_t n = A.n_loc;
   for (int i = i0 + lane; i < i1; i += 64) {
     const double s0 = A.scale[3 * (int64_t)i], s1 = A.scale[3 * (int64_t)i + 1], s2 = A.scale[3 * (int64_t)i + 2];
-    const double a0 = s0 > 0.0 ? 1.0 / s0 : 0.0, a1 = s1 > 0.0 ? 1.0 / s1 : 0.0, a2 = s2 > 0.0 ? 1.0 / s2 : 0.0;
+    // a pose without any edge (an all-zero row of J'J) stays out of the coarse space, like the constant pose: its row of
+    // the system is D'D y = 0, and a correction through its aggregate would move it by rounding noise
+    const bool in_graph = A.hd[i] != 0.0 || A.hd[3 * n + i] != 0.0 || A.hd[5 * n + i] != 0.0;
+    const double a0 = (in_graph && s0 > 0.0) ? 1.0 / s0 : 0.0, a1 = (in_graph && s1 > 0.0) ? 1.0 / s1 : 0.0,
+                 a2 = (in_graph && s2 > 0.0) ? 1.0 / s2 : 0.0;
     A.pb[i] = a0;
     A.pb[n + i] = a1;
     A.pb[2 * n + i] = a2;
@@ -257,23 +261,47 @@ __global__ __launch_bounds__(256) void k_coarse_check(const double* __restrict__
 
 // e_c = Ainv r_c (dense, symmetric, order Kp <= 1024): one wavefront per row, four rows per workgroup; the workgroup's
 // share of r_c . e_c goes to dot_part[blockIdx.x] (fixed order).  Level off: e_c = 0, partials 0.
-template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
-__global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict__ Ainv, int Kp, const double* __restrict__ rc,
-                                                       double* __restrict__ ec, double* __restrict__ dot_part,
+// The restriction r_c = P'r rides along: every workgroup forms the whole r_c in LDS first -- one thread per aggregate,
+// the aggregate's poses in order (a few hundred KB of L2 reads per workgroup on the graphs this path serves) -- which
+// saves the separate k_coarse_restrict launch of a latency-bound PCG iteration (aggregates of <= 32 poses; longer ones
+// would make the one-thread sums the critical path: then r == nullptr and r_c comes from k_coarse_restrict).
+template <int PGO_UNIT_ = 0>
+__global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict__ Ainv, int Kp, int n_loc, int agg, int n_agg,
+                                                       const double* __restrict__ pb, const double* __restrict__ r,
+                                                       const double* __restrict__ rc_in, double* __restrict__ ec, double* __restrict__ dot_part,
                                                        const int32_t* __restrict__ ok, const int32_t* __restrict__ done) {
+  __shared__ double rcs[1024];
   __shared__ double sh[4];
   if (done && *done) return;
+  const int64_t n = n_loc;
+  for (int k = threadIdx.x; k < Kp; k += 256) rcs[k] = r ? 0.0 : rc_in[k];   // r == nullptr: r_c comes from k_coarse_restrict
+  __syncthreads();
+  for (int a = threadIdx.x; r && a < n_agg; a += 256) {
+    const int i0 = a * agg, i1 = min(n_loc, i0 + agg);
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    for (int i = i0; i < i1; ++i) {
+      const PBasis p = pb_load(pb, n, i);
+      const double r0 = r[3 * (int64_t)i], r1 = r[3 * (int64_t)i + 1], r2 = r[3 * (int64_t)i + 2];
+      c0 += p.a0 * r0;
+      c1 += p.a1 * r1;
+      c2 += p.b0 * r0 + p.b1 * r1 + p.a2 * r2;
+    }
+    rcs[3 * a] = c0;
+    rcs[3 * a + 1] = c1;
+    rcs[3 * a + 2] = c2;
+  }
+  __syncthreads();
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   double s = 0.0;
   if (*ok && row < Kp) {
     const double* a = Ainv + (int64_t)row * Kp;
-    for (int c = lane; c < Kp; c += 64) s += a[c] * rc[c];
+    for (int c = lane; c < Kp; c += 64) s += a[c] * rcs[c];
   }
   s = wave_sum_fixed(s);
   if (lane == 0) {
     if (row < Kp) ec[row] = s;
-    sh[w] = (row < Kp) ? s * rc[row] : 0.0;
+    sh[w] = (row < Kp) ? s * rcs[row] : 0.0;
   }
   __syncthreads();
   if (threadIdx.x == 0) dot_part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
     int4 dn = d;
     if (tn < xr.end) dn = A.tile_desc[tn];
     if (nq <= WG) {
-      if (tid <= nrows) sptr[buf][tid] = A.inc_ptr[r0 + tid] - q0;
+      for (int k = tid; k <= nrows; k += WG) sptr[buf][k] = A.inc_ptr[r0 + k] - q0;   // (nrows can be 256: rows without edges)
       int ed_n = 0, col_n = 0, roff_n = 0;
       if (tid < nq) {
         const int q = q0 + tid;

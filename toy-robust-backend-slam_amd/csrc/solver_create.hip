@@ -401,7 +401,9 @@ int pgo_handle::coarse_setup() {
     //   loose solves (the inexact mode) only where the coarse matrix is cheap next to the fine level: 8193 .. 32768 poses
     //   (10k at rtol 0.1: 371 -> 771 with 64-pose aggregates; 100k: 189 -> 80 .. 121, the factorisation of an order-4689
     //   matrix per LM iteration costs more than the PCG iterations it saves).
-    if (direct || NL < 512) return PGO_OK;
+    // ... and only while the caller left the one-level preconditioner to the library (like the direct solve's auto rule): an
+    // explicit pcg_block_poses / pcg_chain_len is a request for exactly that preconditioner
+    if (direct || NL < 512 || opt.pcg_chain_len != -1 || opt.pcg_block_poses != 0) return PGO_OK;
     const bool tight = opt.pcg_rtol <= 1e-3;
     if (!tight && !(NL > 8192 && NL <= 32768)) return PGO_OK;
     want = NL <= 8192 ? 16 : 64;
