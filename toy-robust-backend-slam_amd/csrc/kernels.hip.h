@@ -597,57 +597,41 @@ __device__ __forceinline__ void asm_store_row(const AsmArgs& A, int c, int row, 
   }
 }
 
-// Plain tiles (<= 256 incidences, the rule) run as a two-stage pipeline like K3: the tile's descriptor is ONE 16-byte
-// record, the index triples (edge | column | row offset) of tile t + 1 are requested while tile t is computed, the tile's
-// row pointers wait in LDS for the row phase, and the staging area is double-buffered (one barrier per tile).  Before,
-// a tile cost four dependent round trips (tile_row -> inc_ptr -> inc_edge -> record, plus an 8-step search for the row)
-// and two barriers: 433 us at 1M poses for 1.83 GB of traffic.
+// One workgroup per tile (many workgroups: eight resident per compute unit hide the tile's one dependent round trip --
+// index triple -> record / scales).  Round 3 took two dependent steps out of that chain: the tile's 16-byte descriptor
+// replaces tile_row -> inc_ptr, and the row of an incidence comes from a u8 offset instead of an eight-step binary search
+// in inc_ptr; the tile's row pointers wait in LDS for the row phase.  A persistent, software-pipelined form like K3's (index
+// triples of the next tile prefetched, double-buffered staging, ~1000-1500 workgroups) was built and measured SLOWER:
+// 505 us against 409 us at 1M poses -- with 39 KB of LDS only four workgroups fit a compute unit, and the records
+// themselves (the long pole) were still requested only after the previous tile's barrier.
 template <bool SC, bool INFO>
 __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
   static_assert(!(SC && INFO), "switchable constraints have no information-weighted form here");
   constexpr int NS = SC ? 15 : 9;  // staged values per incidence
-  __shared__ double scr[2][NS][WG];
-  __shared__ int sptr[2][WG + 1];
+  __shared__ double scr[NS][WG];
+  __shared__ int sptr[WG + 1];
   const int tid = threadIdx.x;
   const XcdRange xr = xcd_range(A.n_tiles);
-  int t = xr.begin;
-  if (t >= xr.end) return;
-  int4 d = A.tile_desc[t];
-  int ed = 0, col = 0, roff = 0;
-  if (d.w <= WG && tid < d.w) {
-    ed = A.inc_edge[d.z + tid];
-    col = A.inc_col[d.z + tid];
-    roff = A.inc_rowoff[d.z + tid];
-  }
-  int buf = 0;
-  for (; t < xr.end; t += xr.step) {
+  for (int t = xr.begin; t < xr.end; t += xr.step) {
+    const int4 d = A.tile_desc[t];
     const int r0 = d.x, nrows = d.y, q0 = d.z, nq = d.w;
-    const int tn = t + xr.step;
-    int4 dn = d;
-    if (tn < xr.end) dn = A.tile_desc[tn];
     if (nq <= WG) {
-      for (int k = tid; k <= nrows; k += WG) sptr[buf][k] = A.inc_ptr[r0 + k] - q0;   // (nrows can be 256: rows without edges)
-      int ed_n = 0, col_n = 0, roff_n = 0;
+      for (int k = tid; k <= nrows; k += WG) sptr[k] = A.inc_ptr[r0 + k] - q0;   // (nrows can be 256: rows without edges)
       if (tid < nq) {
         const int q = q0 + tid;
+        const int ed = A.inc_edge[q], col = A.inc_col[q], roff = A.inc_rowoff[q];
         const bool first_of_pair = tid == 0 || roff != (int)A.inc_rowoff[q - 1] || A.inc_col[q - 1] != col;
-        asm_incidence<SC, INFO>(A, q, ed, (int64_t)col, r0 + roff, first_of_pair, tid, scr[buf]);
-      }
-      if (tn < xr.end && dn.w <= WG && tid < dn.w) {   // (the descriptor was this iteration's first load)
-        ed_n = A.inc_edge[dn.z + tid];
-        col_n = A.inc_col[dn.z + tid];
-        roff_n = A.inc_rowoff[dn.z + tid];
+        asm_incidence<SC, INFO>(A, q, ed, (int64_t)col, r0 + roff, first_of_pair, tid, scr);
       }
       __syncthreads();
       for (int idx = tid; idx < nrows * NS; idx += WG) {
         const int c = idx / nrows, rl = idx - c * nrows;
-        const int lo = sptr[buf][rl], hi = sptr[buf][rl + 1];
+        const int lo = sptr[rl], hi = sptr[rl + 1];
         double s = 0.0;
-        for (int j = lo; j < hi; ++j) s += scr[buf][c][j];
+        for (int j = lo; j < hi; ++j) s += scr[c][j];
         asm_store_row<SC>(A, c, r0 + rl, s);
       }
-      buf ^= 1;
-      ed = ed_n; col = col_n; roff = roff_n;
+      __syncthreads();
     } else {
       // ---- one heavy row (> 256 incidences): chunks of 256, two barriers per chunk, the sums carried in registers
       const int q1 = q0 + nq;
@@ -658,25 +642,19 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
           const int e2 = A.inc_edge[q];
           const int c2 = A.inc_col[q];
           const bool first_of_pair = q == q0 || A.inc_col[q - 1] != c2;
-          asm_incidence<SC, INFO>(A, q, e2, (int64_t)c2, r0, first_of_pair, tid, scr[buf]);
+          asm_incidence<SC, INFO>(A, q, e2, (int64_t)c2, r0, first_of_pair, tid, scr);
         }
         __syncthreads();
         if (tid < NS) {
           const int hi = min(q1, base + WG) - base;
           double s = 0.0;
-          for (int j = 0; j < hi; ++j) s += scr[buf][tid][j];
+          for (int j = 0; j < hi; ++j) s += scr[tid][j];
           acc += s;
         }
         __syncthreads();
       }
       if (tid < NS) asm_store_row<SC>(A, tid, r0, acc);
-      if (tn < xr.end && dn.w <= WG && tid < dn.w) {
-        ed = A.inc_edge[dn.z + tid];
-        col = A.inc_col[dn.z + tid];
-        roff = A.inc_rowoff[dn.z + tid];
-      }
     }
-    d = dn;
   }
 }
 

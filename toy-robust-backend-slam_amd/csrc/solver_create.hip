@@ -141,7 +141,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   g_flat = std::min(std::max(1, cdiv(3 * NL, dev::WG)), 1024);
   if (const char* fe = PGO_EXP_ENV("PGO_FLAT_GRID")) g_flat = std::min(g_flat, std::max(8, atoi(fe)));
   g_spmv = up8(std::min(std::max(1, S.n_tiles()), 2048));
-  g_asm = up8(std::min(std::max(1, S.n_tiles()), 256 * 6));   // persistent workgroups: the pipelined K2 walks ~20 tiles each at 1M poses
+  g_asm = up8(std::min(std::max(1, S.n_tiles()), 1 << 20));
   part_cap = std::max(g_edge, 2048) + 8 + 512;   // (+ the coarse level's dot partials behind the one-level r.z partials)
   for (int k = 0; k < N_PART; ++k) PGOC(dalloc(&part[k], part_cap));
 

@@ -325,12 +325,11 @@ int pgo_handle::prepare_preconditioner() {
 // block LDL' of the chain preconditioner's segments (the records are complete: C part from k_assemble, M part from k_prepare)
 int pgo_handle::factor_chain() {
   const int n_seg = (S.n_loc + chain_len - 1) / chain_len;
-  // One THREAD per segment runs the recurrence (64 .. 256 dependent steps), so the kernel lives on memory requests in
-  // flight, not on lanes: with 64 segments per wavefront the 15.6k segments of the 1M-pose graph are 244 wavefronts --
-  // one per compute unit, 32 KB in flight each, 0.25 of the HBM roofline.  16 segments per wavefront (4 wavefronts per
-  // compute unit, each with its own queue of outstanding loads) quadruple that.
-  int spw = 64;
-  while (spw > 8 && n_seg / spw < 1024) spw >>= 1;
+  // One THREAD per segment runs the recurrence (64 .. 256 dependent steps), 64 segments per wavefront: 244 wavefronts at 1M
+  // poses.  Fewer segments per wavefront (16: four wavefronts per compute unit, each with its own queue of outstanding loads)
+  // were measured SLOWER -- 233 us against 123 us: the same 128-byte-per-lane record loads then take four times as many
+  // wave instructions through the address coalescer, and 174 instead of 122 MB are written.
+  const int spw = 64;
   if ((chain_chunk ? chain_chunk : dev::CHAIN_CHUNK) == 2)
     hipLaunchKernelGGL(dev::k_chain_factor<2>, dim3((n_seg + spw - 1) / spw), dim3(spw), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
                        chain_len, chain_w, chain_s);
