@@ -205,8 +205,7 @@ typedef struct pgo_options {
                                   -1 (default) = auto, for graphs of >= 512 poses that stay on PCG while pcg_block_poses and
                                   pcg_chain_len are left at auto: on for tight solves
                                   (pcg_rtol <= 1e-3) -- 16 poses per aggregate up to 8192 poses, else 64, doubled until the
-                                  coarse order fits -- and for loose solves of 8193 .. 32768 poses (64), where the dense
-                                  coarse factorisation is cheap next to the PCG iterations it saves                     */
+                                  coarse order fits; loose solves (the inexact mode) stay on one level unless asked        */
 } pgo_options;
 
 void pgo_options_default(pgo_options* o);                                  /* [host] */

@@ -261,128 +261,44 @@ __global__ __launch_bounds__(256) void k_coarse_check(const double* __restrict__
 
 // e_c = Ainv r_c (dense, symmetric, order Kp <= 1024): one wavefront per row, four rows per workgroup; the workgroup's
 // share of r_c . e_c goes to dot_part[blockIdx.x] (fixed order).  Level off: e_c = 0, partials 0.
-// The restriction r_c = P'r rides along: every workgroup forms the whole r_c in LDS first -- one thread per aggregate,
-// the aggregate's poses in order (a few hundred KB of L2 reads per workgroup on the graphs this path serves) -- which
-// saves the separate k_coarse_restrict launch of a latency-bound PCG iteration (aggregates of <= 32 poses; longer ones
-// would make the one-thread sums the critical path: then r == nullptr and r_c comes from k_coarse_restrict).
+// (Folding the restriction into this kernel's prologue -- every workgroup forming r_c in LDS, one thread per aggregate --
+// saves a launch and was measured slower: M3500 METHOD 1 113 against 156 GN it/s.)
 template <int PGO_UNIT_ = 0>
-__global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict__ Ainv, int Kp, int n_loc, int agg, int n_agg,
-                                                       const double* __restrict__ pb, const double* __restrict__ r,
-                                                       const double* __restrict__ rc_in, double* __restrict__ ec, double* __restrict__ dot_part,
+__global__ __launch_bounds__(256) void k_coarse_matvec(const double* __restrict__ Ainv, int Kp, const double* __restrict__ rc,
+                                                       double* __restrict__ ec, double* __restrict__ dot_part,
                                                        const int32_t* __restrict__ ok, const int32_t* __restrict__ done) {
-  __shared__ double rcs[1024];
   __shared__ double sh[4];
   if (done && *done) return;
-  const int64_t n = n_loc;
-  for (int k = threadIdx.x; k < Kp; k += 256) rcs[k] = r ? 0.0 : rc_in[k];   // r == nullptr: r_c comes from k_coarse_restrict
-  __syncthreads();
-  for (int a = threadIdx.x; r && a < n_agg; a += 256) {
-    const int i0 = a * agg, i1 = min(n_loc, i0 + agg);
-    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-    for (int i = i0; i < i1; ++i) {
-      const PBasis p = pb_load(pb, n, i);
-      const double r0 = r[3 * (int64_t)i], r1 = r[3 * (int64_t)i + 1], r2 = r[3 * (int64_t)i + 2];
-      c0 += p.a0 * r0;
-      c1 += p.a1 * r1;
-      c2 += p.b0 * r0 + p.b1 * r1 + p.a2 * r2;
-    }
-    rcs[3 * a] = c0;
-    rcs[3 * a + 1] = c1;
-    rcs[3 * a + 2] = c2;
-  }
-  __syncthreads();
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   double s = 0.0;
   if (*ok && row < Kp) {
     const double* a = Ainv + (int64_t)row * Kp;
-    for (int c = lane; c < Kp; c += 64) s += a[c] * rcs[c];
+    for (int c = lane; c < Kp; c += 64) s += a[c] * rc[c];
   }
   s = wave_sum_fixed(s);
   if (lane == 0) {
     if (row < Kp) ec[row] = s;
-    sh[w] = (row < Kp) ? s * rcs[row] : 0.0;
+    sh[w] = (row < Kp) ? s * rc[row] : 0.0;
   }
   __syncthreads();
   if (threadIdx.x == 0) dot_part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// ---- large coarse orders: the two triangular products N'(N r_c) cut into tiles of 32 rows x TRI_CW columns (N x) /
-// TRI_CW rows x 32 columns (N' y), one workgroup each, so that a few hundred workgroups share the factor's 88 MB (order
-// 4689) evenly -- with one workgroup per block row (k_tri_apply) the last rows set the pace.  Partial sums are written per
-// tile and added in tile order by the consumer: a fixed order, bitwise reproducible.
-constexpr int TRI_CW = 512;
-// tiles of y = N x: tile list entry t = (block row b, column chunk j); part_a[(b * n_chunk + j) * 32 + row]
-template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
-__global__ __launch_bounds__(256) void k_tri_tiles_a(const double* __restrict__ Nm, int ld, const int2* __restrict__ tiles,
-                                                            const double* __restrict__ x, double* __restrict__ part_a, int n_chunk,
-                                                            const int32_t* __restrict__ done) {
-  if (done && *done) return;
-  const int2 t = tiles[blockIdx.x];
-  const int b = t.x, j = t.y;
-  const int r = threadIdx.x >> 3, p = threadIdx.x & 7;
-  const int c0 = j * TRI_CW, c1 = min(32 * (b + 1), c0 + TRI_CW);
-  const double* row = Nm + (int64_t)(32 * b + r) * ld;
-  double s = 0.0;
-#pragma unroll 8
-  for (int c = c0 + p; c < c1; c += 8) s += row[c] * x[c];
-  s += __shfl_xor(s, 1, 8);
-  s += __shfl_xor(s, 2, 8);
-  s += __shfl_xor(s, 4, 8);
-  if (p == 0) part_a[((int64_t)b * n_chunk + j) * 32 + r] = s;
-}
-// tiles of z = N' y with y = the sum of part_a's chunks: tile (column block b, row chunk i): rows [i TRI_CW, (i + 1) TRI_CW)
-// from 32 b on; part_b[(b * n_chunk + i) * 32 + column]
-template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
-__global__ __launch_bounds__(256) void k_tri_tiles_b(const double* __restrict__ Nm, int ld, int nb, const int2* __restrict__ tiles,
-                                                            const double* __restrict__ part_a, double* __restrict__ part_b, int n_chunk,
-                                                            const int32_t* __restrict__ done) {
-  __shared__ double ys[TRI_CW];
-  __shared__ double red[8][32];
-  if (done && *done) return;
-  const int2 t = tiles[blockIdx.x];
-  const int b = t.x, i = t.y;
-  const int r0 = max(32 * b, i * TRI_CW), r1 = min(32 * nb, (i + 1) * TRI_CW);
-  // y of the chunk's rows: chunks 0 .. (columns of that block row) in order
-  for (int k = threadIdx.x; k < r1 - r0; k += 256) {
-    const int rr = r0 + k, br = rr >> 5;
-    const int nch = (32 * (br + 1) + TRI_CW - 1) / TRI_CW;
-    double v = 0.0;
-    for (int jj = 0; jj < nch; ++jj) v += part_a[((int64_t)br * n_chunk + jj) * 32 + (rr & 31)];
-    ys[k] = v;
-  }
-  __syncthreads();
-  const int c = threadIdx.x & 31, p = threadIdx.x >> 5;
-  double s = 0.0;
-#pragma unroll 8
-  for (int rr = r0 + p; rr < r1; rr += 8) s += Nm[(int64_t)rr * ld + 32 * b + c] * ys[rr - r0];
-  red[p][c] = s;
-  __syncthreads();
-  if (p == 0) {
-    double v = red[0][c];
-#pragma unroll
-    for (int q = 1; q < 8; ++q) v += red[q][c];
-    part_b[((int64_t)b * n_chunk + i) * 32 + c] = v;
-  }
-}
-// e_c = the sum of part_b's chunks (level off: 0) and the partials of r_c . e_c, 256 entries per workgroup
-template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
-__global__ __launch_bounds__(256) void k_tri_finish(int Kp, int nb, int n_chunk, const double* __restrict__ part_b,
-                                                           const double* __restrict__ rc, double* __restrict__ ec,
-                                                           double* __restrict__ dot_part, const int32_t* __restrict__ ok,
-                                                           const int32_t* __restrict__ done) {
+// larger orders, after the two triangular products N'(N r_c) (k_tri_apply): partials of r_c . e_c, 256 entries per
+// workgroup; level off: e_c = 0.  (Cutting the two products into 32 x 512 tiles over a few hundred workgroups was measured
+// equal -- 100k poses, order 4689: 12.2 against 12.3 GN it/s -- the products are bound by reading the 88 MB factor twice.)
+template <int PGO_UNIT_ = 0>
+__global__ __launch_bounds__(256) void k_coarse_dot(int Kp, const double* __restrict__ rc, double* __restrict__ ec,
+                                                    double* __restrict__ dot_part, const int32_t* __restrict__ ok,
+                                                    const int32_t* __restrict__ done) {
   __shared__ double red[8];
   if (done && *done) return;
   const int k = blockIdx.x * 256 + threadIdx.x;
   double v = 0.0;
   if (k < Kp) {
-    double e = 0.0;
-    if (*ok) {
-      const int b = k >> 5;
-      for (int i = (32 * b) / TRI_CW; i * TRI_CW < 32 * nb; ++i) e += part_b[((int64_t)b * n_chunk + i) * 32 + (k & 31)];
-    }
-    ec[k] = e;
-    v = rc[k] * e;
+    if (!*ok) ec[k] = 0.0;
+    else v = rc[k] * ec[k];
   }
   v = block_sum_bcast(v, red);
   if (threadIdx.x == 0) dot_part[blockIdx.x] = v;

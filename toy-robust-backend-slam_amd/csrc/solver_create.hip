@@ -398,14 +398,12 @@ int pgo_handle::coarse_setup() {
     //   order 657; 32: 128, 64: 100), FRH 35 -> 199 (16), synthetic 10k at 1e-10 108 -> 137 (64; 16: 127), 100k at 1e-10
     //   3.7 -> 12.3 and at 1e-3 14.9 -> 40.5 (64, order 4689; 128 and more: no gain) -- 16 poses up to 8192 poses, else
     //   64, doubled until the coarse order fits the dense factorisation;
-    //   loose solves (the inexact mode) only where the coarse matrix is cheap next to the fine level: 8193 .. 32768 poses
-    //   (10k at rtol 0.1: 371 -> 771 with 64-pose aggregates; 100k: 189 -> 80 .. 121, the factorisation of an order-4689
-    //   matrix per LM iteration costs more than the PCG iterations it saves).
+    //   loose solves (the inexact mode) stay on one level: measured both ways -- synthetic 10k at rtol 0.1, 64-pose aggregates:
+    //   371 -> 771 over a long run at large radius, but 582 -> 530 over the first 50 LM iterations, where a solve needs few PCG
+    //   iterations anyway and the coarse factorisation per LM iteration is pure overhead; 100k: 189 -> 80 .. 121.
     // ... and only while the caller left the one-level preconditioner to the library (like the direct solve's auto rule): an
     // explicit pcg_block_poses / pcg_chain_len is a request for exactly that preconditioner
-    if (direct || NL < 512 || opt.pcg_chain_len != -1 || opt.pcg_block_poses != 0) return PGO_OK;
-    const bool tight = opt.pcg_rtol <= 1e-3;
-    if (!tight && !(NL > 8192 && NL <= 32768)) return PGO_OK;
+    if (direct || NL < 512 || opt.pcg_chain_len != -1 || opt.pcg_block_poses != 0 || !(opt.pcg_rtol <= 1e-3)) return PGO_OK;
     want = NL <= 8192 ? 16 : 64;
     while (3 * ((NL + want - 1) / want) + 1 > COARSE_MAX_RANK) want *= 2;
   }
@@ -467,26 +465,6 @@ int pgo_handle::coarse_setup() {
   PGOC(dalloc(&co_ok, 1));
   if (co_Kp <= COARSE_EXPLICIT_RANK) PGOC(dalloc(&co_ainv, (int64_t)co_Kp * co_Kp));
   co_ndot = co_ainv ? (co_Kp + 3) / 4 : (co_Kp + 255) / 256;
-  if (!co_ainv) {   // tiles of the two triangular products
-    const int nb = co_Kp / 32;
-    co_nchunk = (co_Kp + dev::TRI_CW - 1) / dev::TRI_CW;
-    std::vector<int2> ta, tb;
-    for (int b = 0; b < nb; ++b) {
-      for (int j = 0; j * dev::TRI_CW < 32 * (b + 1); ++j) ta.push_back(make_int2(b, j));
-      for (int i = (32 * b) / dev::TRI_CW; i * dev::TRI_CW < 32 * nb; ++i) tb.push_back(make_int2(b, i));
-    }
-    co_nta = (int)ta.size();
-    co_ntb = (int)tb.size();
-    PGOC(dalloc(&co_tiles_a, co_nta));
-    PGOC(dalloc(&co_tiles_b, co_ntb));
-    PGOC(dalloc(&co_part_a, (int64_t)nb * co_nchunk * 32));
-    PGOC(dalloc(&co_part_b, (int64_t)nb * co_nchunk * 32));
-    PGOC(upload(co_tiles_a, ta));
-    PGOC(upload(co_tiles_b, tb));
-    PGOC(sync());   // the lists die with this scope
-  }
-  if (g_chain + co_ndot + 8 > part_cap || g_grp + co_ndot + 8 > part_cap || g_vec + co_ndot + 8 > part_cap)
-    return no("internal: not enough room for the coarse level's dot partials");
   PGOC(dalloc(&co_cb_i, co_ncb));
   PGOC(dalloc(&co_cb_j, co_ncb));
   PGOC(dalloc(&co_cb_ptr, co_ncb + 1));

@@ -134,9 +134,6 @@ struct pgo_handle {
   int coarse_setup();      // create: aggregates, coarse block lists, buffers
   int coarse_factor();     // per LM iteration: basis, Galerkin matrix, Cholesky + inverse factor
   double* co_ainv = nullptr;   // explicit inverse N'N (coarse orders <= COARSE_EXPLICIT_RANK: one product per apply)
-  int2 *co_tiles_a = nullptr, *co_tiles_b = nullptr;   // larger orders: tiles of the two triangular products (k_tri_tiles_*)
-  double *co_part_a = nullptr, *co_part_b = nullptr;
-  int co_nta = 0, co_ntb = 0, co_nchunk = 0;
   int32_t* co_ok = nullptr;    // device flag: the factorisation of this LM iteration is usable
   int co_ndot = 0;             // partials of r_c . e_c appended to the r.z partials
   int coarse_solve(double* dot_part, const int32_t* done);   // e_c = (P'(H + D'D)P)^-1 P' r  (+ partials of r_c . e_c)

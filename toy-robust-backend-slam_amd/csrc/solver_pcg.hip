@@ -57,23 +57,16 @@ int pgo_handle::coarse_factor() {
 
 int pgo_handle::coarse_solve(double* dot_part, const int32_t* done) {
   const int nb = co_Kp / 32;
-  if (co_ainv) {   // (short aggregates: the restriction rides in the product's prologue)
-    const bool fused_restrict = co_agg <= 32;
-    if (!fused_restrict)
-      hipLaunchKernelGGL(dev::k_coarse_restrict<>, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, (int)S.n_loc, co_agg, co_nagg, (const double*)co_pb,
-                         (const double*)r, co_rc, done);
-    hipLaunchKernelGGL(dev::k_coarse_matvec<>, dim3(co_ndot), dim3(256), 0, stream, (const double*)co_ainv, co_Kp, (int)S.n_loc, co_agg, co_nagg,
-                       (const double*)co_pb, fused_restrict ? (const double*)r : (const double*)nullptr, (const double*)co_rc, co_ec, dot_part,
-                       (const int32_t*)co_ok, done);
+  hipLaunchKernelGGL(dev::k_coarse_restrict<>, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, (int)S.n_loc, co_agg, co_nagg, (const double*)co_pb,
+                     (const double*)r, co_rc, done);
+  if (co_ainv) {
+    hipLaunchKernelGGL(dev::k_coarse_matvec<>, dim3(co_ndot), dim3(256), 0, stream, (const double*)co_ainv, co_Kp, (const double*)co_rc, co_ec,
+                       dot_part, (const int32_t*)co_ok, done);
   } else {
-    hipLaunchKernelGGL(dev::k_coarse_restrict<>, dim3((co_nagg + 3) / 4), dim3(256), 0, stream, (int)S.n_loc, co_agg, co_nagg, (const double*)co_pb,
-                       (const double*)r, co_rc, done);
-    hipLaunchKernelGGL(dev::k_tri_tiles_a<>, dim3(co_nta), dim3(256), 0, stream, (const double*)co_nm, co_Kp, (const int2*)co_tiles_a,
-                       (const double*)co_rc, co_part_a, co_nchunk, done);
-    hipLaunchKernelGGL(dev::k_tri_tiles_b<>, dim3(co_ntb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const int2*)co_tiles_b,
-                       (const double*)co_part_a, co_part_b, co_nchunk, done);
-    hipLaunchKernelGGL(dev::k_tri_finish<>, dim3(co_ndot), dim3(256), 0, stream, co_Kp, nb, co_nchunk, (const double*)co_part_b,
-                       (const double*)co_rc, co_ec, dot_part, (const int32_t*)co_ok, done);
+    hipLaunchKernelGGL(dev::k_tri_apply<>, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_rc, co_cy, 0);
+    hipLaunchKernelGGL(dev::k_tri_apply<>, dim3(nb), dim3(256), 0, stream, (const double*)co_nm, co_Kp, nb, (const double*)co_cy, co_ec, 1);
+    hipLaunchKernelGGL(dev::k_coarse_dot<>, dim3(co_ndot), dim3(256), 0, stream, co_Kp, (const double*)co_rc, co_ec, dot_part,
+                       (const int32_t*)co_ok, done);
   }
   return check_launch("coarse level solve");
 }
