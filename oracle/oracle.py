@@ -546,6 +546,87 @@ def lm_pcg(g: Graph, opt: Options = Options(), variant=None) -> Result:
     return out
 
 
+def pcg_iterations(g: Graph, poses, poses0, radius: float, method: int = 1, rtol: float = 1e-10, block_poses: int = 32,
+                   coarse_poses: int = 0, fixed_pose: int = 0, phi: float = 0.5, delta: float = 0.01, max_iters: int = 200000):
+    """Restatement (numpy / scipy) of ONE linear solve of the PCG path at the LM state (poses, radius), for checking the
+    preconditioners' iteration counts independently of the HIP kernels: the Jacobi-scaled system ((JS)'(JS) + D'D) y = S J'r
+    with S from the Jacobian at `poses0` (Ceres: iteration 0), D'D = clamp(diag) / radius (identity on the constant pose);
+    preconditioner = block-Jacobi over groups of `block_poses` consecutive poses (exact solves of the diagonal blocks) plus,
+    for coarse_poses > 0, the additive coarse correction P (P'AP)^-1 P' on the rigid-body modes of aggregates of
+    `coarse_poses` consecutive poses (translation x, y, rotation about the aggregate's centre; in scaled variables
+    P_i = S_i^-1 B_i -- the second level of toy-robust-backend-slam_amd/csrc/coarse.hip.h, solved exactly here).
+    Returns (PCG iterations to |r| <= rtol |b| from y = 0, solution y)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    N, E = g.n_poses, g.n_edges
+    rows = np.repeat(np.arange(3 * E).reshape(E, 3), 6, axis=1).reshape(-1)
+    cols = np.concatenate([3 * g.ia[:, None] + np.arange(3), 3 * g.ib[:, None] + np.arange(3)], axis=1)
+    cols = np.tile(cols, (1, 3)).reshape(-1).astype(np.int64)
+
+    def jac(p):
+        _, r, J = evaluate(g, np.asarray(p, np.float64), method, phi, delta, True, True, True, 1)
+        return sp.csr_matrix((J.reshape(-1), (rows, cols)), shape=(3 * E, 3 * N)), r.reshape(-1)
+
+    A0, _ = jac(poses0)
+    s = 1.0 / (1.0 + np.sqrt(np.asarray(A0.multiply(A0).sum(axis=0)).reshape(-1)))
+    if fixed_pose >= 0:
+        s[3 * fixed_pose:3 * fixed_pose + 3] = 0.0
+    A, r = jac(poses)
+    AS = A @ sp.diags(s)
+    H = (AS.T @ AS).tocsr()
+    d2 = np.clip(H.diagonal(), 1e-6, 1e32) / radius
+    if fixed_pose >= 0:
+        d2[3 * fixed_pose:3 * fixed_pose + 3] = 1.0
+    H = (H + sp.diags(d2)).tocsr()
+    b = AS.T @ r
+    C = H.tocoo()
+    grp = np.arange(3 * N) // (3 * block_poses)
+    m = grp[C.row] == grp[C.col]
+    M1 = spla.splu(sp.csc_matrix((C.data[m], (C.row[m], C.col[m])), shape=H.shape))
+    apply_m = M1.solve
+    if coarse_poses > 0:
+        x = np.asarray(poses, np.float64).reshape(N, 3)
+        agg = np.arange(N) // coarse_poses
+        na = int(agg.max()) + 1
+        cnt = np.bincount(agg, minlength=na)
+        cx, cy = np.bincount(agg, x[:, 0], na) / cnt, np.bincount(agg, x[:, 1], na) / cnt
+        in_graph = np.asarray(H.diagonal() - d2).reshape(N, 3).any(axis=1)       # poses without edges stay out
+        sinv = np.where(s > 0, 1.0 / np.where(s > 0, s, 1.0), 0.0) * np.repeat(in_graph, 3)
+        i = np.arange(N)
+        pr = [3 * i, 3 * i + 1, 3 * i + 2, 3 * i, 3 * i + 1]
+        pc = [3 * agg, 3 * agg + 1, 3 * agg + 2, 3 * agg + 2, 3 * agg + 2]
+        pv = [sinv[3 * i], sinv[3 * i + 1], sinv[3 * i + 2], -(x[:, 1] - cy[agg]) * sinv[3 * i], (x[:, 0] - cx[agg]) * sinv[3 * i + 1]]
+        P = sp.csr_matrix((np.concatenate(pv), (np.concatenate(pr), np.concatenate(pc))), shape=(3 * N, 3 * na))
+        Ac = (P.T @ H @ P).toarray()
+        dead = np.diag(Ac) == 0.0                      # an aggregate made of constant / edge-less poses only
+        Ac[dead, dead] = 1.0
+        Lc = np.linalg.cholesky(Ac)
+
+        def apply_m(rv):
+            rc = P.T @ rv
+            ec = np.linalg.solve(Lc.T, np.linalg.solve(Lc, rc))
+            return M1.solve(rv) + P @ ec
+    y = np.zeros_like(b)
+    rv = b.copy()
+    z = apply_m(rv)
+    p = z.copy()
+    rz = rv @ z
+    bn = np.linalg.norm(b)
+    for k in range(1, max_iters + 1):
+        Ap = H @ p
+        alpha = rz / (p @ Ap)
+        y += alpha * p
+        rv -= alpha * Ap
+        if np.linalg.norm(rv) <= rtol * bn:
+            return k, y
+        z = apply_m(rv)
+        rz2 = rv @ z
+        p = z + (rz2 / rz) * p
+        rz = rz2
+    return max_iters, y
+
+
 def lm_direct_sc(g: Graph, opt: Options = Options(), lam: float = 1.0) -> Result:
     """METHOD 2 (switchable constraints): the same Ceres policy as lm_direct on the joint parameter vector
     [poses; one switch per closure/bogus edge (initialised to 1.0)], residual blocks as in pgo_oracle_eval_sc,

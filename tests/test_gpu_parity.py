@@ -355,6 +355,31 @@ def test_two_level_preconditioner(pgo, name, method):
     one.close(); two.close()
 
 
+@pytest.mark.parametrize("name,method", [("M3500", 1), ("FRH", 1)])
+def test_two_level_pcg_iteration_counts_match_the_restatement(pgo, oracle, name, method):
+    """the second preconditioner level against an independent restatement: oracle.pcg_iterations builds the same scaled system
+    with scipy, block-Jacobi over 32-pose groups by exact solves, the rigid-body coarse space of 16-pose aggregates with an
+    exact dense solve, and runs textbook PCG -- the HIP path must need the same number of iterations for the third LM
+    iteration's solve (one level: the known count of the C port; two levels: within 3 %), and land on the same solution"""
+    g = load(pgo, name)
+    og = oracle_graph(oracle, g)
+    x0 = np.array(g.poses)
+    for coarse in (0, 16):
+        kw = dict(method=method, linear_solver=1, pcg_coarse_poses=coarse, pcg_max_iters=400000)
+        s2 = pgo.Solver(g, pgo.Options(max_iters=2, **kw))
+        s2.solve()
+        x2, radius = s2.poses(), s2.iter_records()[-1]["radius"]
+        assert s2.info().pcg_block_poses == 32 and s2.info().pcg_coarse_poses == coarse
+        s2.close()
+        s3 = pgo.Solver(g, pgo.Options(max_iters=3, **kw))
+        s3.solve()
+        k_gpu = s3.iter_records()[3]["pcg_iters"]
+        s3.close()
+        k_ref, _ = oracle.pcg_iterations(og, x2, x0, radius, method=method, rtol=1e-10, block_poses=32, coarse_poses=coarse)
+        print("%s METHOD %d, LM iteration 3, coarse %d: PCG iterations HIP %d, restatement %d" % (name, method, coarse, k_gpu, k_ref))
+        assert abs(k_gpu - k_ref) <= max(2, 0.03 * k_ref)
+
+
 def test_two_level_preconditioner_on_synthetic_graphs(pgo, oracle):
     """the same on a synthetic graph (30011 poses: dense 4-pose blocks as the first level, aggregates chosen by the library),
     tight and loose tolerances: identical accept / reject history, fewer PCG iterations; an explicit
