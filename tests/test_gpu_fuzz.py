@@ -125,6 +125,55 @@ def test_direct_solve_is_taken_or_refused_never_replaced(pgo, case):
     s.close(); ref.close()
 
 
+@settings(**dict(SETTINGS, max_examples=20))
+@given(pose_graphs(), st.sampled_from([3, 8, 16, 50]))
+def test_coarse_level_and_single_reduction_loop_on_arbitrary_graphs(pgo, case, agg):
+    """the round-3 solver paths on graphs they were not tuned on (several components, edge-less poses, hubs, a constant pose
+    anywhere or none, aggregates that do not divide anything): a tight solve with the second preconditioner level and a
+    solve with the one-reduction PCG loop must both land where the plain one-level, two-reduction solve lands -- a
+    preconditioner or a reformulated recurrence may change the iteration count, never the answer"""
+    poses, ia, ib, meas, kind, fixed, method = case
+    if len(ia) == 0:
+        return
+    g = pgo.Graph.from_arrays(poses, ia, ib, meas, kind)
+    kw = dict(method=method, fixed_pose=fixed, max_iters=3, pcg_rtol=1e-12, pcg_max_iters=200000, linear_solver=1)
+    ref = pgo.Solver(g, pgo.Options(pcg_coarse_poses=0, **kw))
+    sr = ref.solve()
+    two = pgo.Solver(g, pgo.Options(pcg_coarse_poses=agg, **kw))
+    s2 = two.solve()
+    assert two.info().pcg_coarse_poses == agg and two.info().pcg_coarse_rank == 3 * ((len(poses) + agg - 1) // agg)
+    assert [r["step_ok"] for r in two.iter_records()] == [r["step_ok"] for r in ref.iter_records()]
+    assert s2.final_cost == pytest.approx(sr.final_cost, rel=1e-7, abs=1e-12)
+    assert np.abs(two.poses() - ref.poses()).max() < 1e-6 * max(1.0, np.abs(ref.poses()).max())
+    assert all(r["iter"] == 0 or r["pcg_rel_residual"] <= 1e-12 for r in two.iter_records())
+    if fixed >= 0:
+        np.testing.assert_array_equal(two.poses()[fixed], poses[fixed])
+    ref.close(); two.close()
+    # the one-reduction loop needs the chain preconditioner and the inexact mode; one rank through the test hook
+    if len(poses) >= 8 and method != 2:
+        kw2 = dict(method=method, fixed_pose=fixed, max_iters=3, pcg_rtol=1e-6, pcg_max_iters=200000, linear_solver=1, pcg_chain_len=8,
+                   pcg_coarse_poses=0)
+        a = pgo.Solver(g, pgo.Options(**kw2))
+        sa = a.solve()
+        pgo.set_knob("single_reduction", 1)
+        pgo.set_knob("fused_p", 0)
+        try:
+            b = pgo.Solver(g, pgo.Options(**kw2))
+        finally:
+            pgo.set_knob("single_reduction", -1)
+            pgo.set_knob("fused_p", -1)
+        sb = b.solve()
+        assert b.info().pcg_single_reduction == 1 and a.info().pcg_single_reduction == 0
+        # both solves stop at |r| <= 1e-6 |b|, possibly an iteration apart: equal up to what that tolerance leaves open
+        assert [r["step_ok"] for r in a.iter_records()] == [r["step_ok"] for r in b.iter_records()]
+        for ra, rb in zip(a.iter_records(), b.iter_records()):
+            assert abs(ra["pcg_iters"] - rb["pcg_iters"]) <= 3 + 0.1 * ra["pcg_iters"]   # (rtol 1e-6 is the loop's guard: the recurrences differ most here)
+            assert ra["iter"] == 0 or rb["pcg_rel_residual"] <= 1e-6
+        assert sb.final_cost == pytest.approx(sa.final_cost, rel=1e-3, abs=1e-12)
+        assert np.abs(a.poses() - b.poses()).max() < 1e-2 * max(1.0, np.abs(a.poses()).max())
+        a.close(); b.close()
+
+
 def test_mit_distance_from_the_fixture_is_the_conditioning(pgo):
     """MIT METHOD 1 runs at a trust-region radius of ~3e11, where the LM systems are so ill-conditioned that ANY two accurate
     solves end ~1e-6 apart after 50 iterations: two independent HIP solves -- PCG to 1e-13 and the direct chain + low-rank
