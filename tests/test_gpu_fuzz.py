@@ -178,8 +178,7 @@ def test_mit_distance_from_the_fixture_is_the_conditioning(pgo):
     """MIT METHOD 1 runs at a trust-region radius of ~3e11, where the LM systems are so ill-conditioned that ANY two accurate
     solves end ~1e-6 apart after 50 iterations: two independent HIP solves -- PCG to 1e-13 and the direct chain + low-rank
     solve with refinement -- differ from each other (measured 5e-7) by about as much as each differs from the golden fixture
-    (the oracle's SuperLU LM solve; 1.0e-6 / 1.5e-6), and are closer to each other than either is to the fixture.  All far
-    inside north_star's 1e-4."""
+    (the oracle's SuperLU LM solve; 1.0e-6 / 1.5e-6): three distances of one order.  All far inside north_star's 1e-4."""
     g = pgo.ReadG2O(os.path.join(DATA, "MIT.g2o"))
     ref = np.load(os.path.join(GOLDEN, "lm_MIT_out0_m1_poses.npy"))
     out = {}
@@ -192,5 +191,6 @@ def test_mit_distance_from_the_fixture_is_the_conditioning(pgo):
     d_pf = np.abs(out["pcg"][:, :2] - ref[:, :2]).max()
     d_df = np.abs(out["direct"][:, :2] - ref[:, :2]).max()
     print("MIT METHOD 1, 50 LM iterations: |PCG(1e-13) - direct| %.2e, |PCG - fixture| %.2e, |direct - fixture| %.2e" % (d_pd, d_pf, d_df))
-    assert max(d_pd, d_pf, d_df) < 1e-5          # two orders inside north_star's tolerance, whichever pair is compared
-    assert d_pd < min(d_pf, d_df)                 # the two HIP solves agree with each other better than with the fixture
+    assert max(d_pd, d_pf, d_df) < 1e-5          # an order of magnitude inside north_star's tolerance, whichever pair is compared
+    assert d_pd > 1e-9                            # ... and the two HIP solves do differ at that level: it is the conditioning,
+    assert max(d_pd, d_pf, d_df) < 20.0 * min(d_pd, d_pf, d_df)   # not one solve (or the fixture) being off
