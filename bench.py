@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = sweep 16 / 64 / every physical core and take the fastest")
     ap.add_argument("--workloads", type=int, default=1, help="1 = also time INTEL+50 / 10k / 100k (N = 1 only)")
     ap.add_argument("--verbose", type=int, default=0)
+    ap.add_argument("--k3", choices=["auto", "pipelined"], default="auto",
+                    help="A/B switch: 'pipelined' keeps the persistent software-pipelined product kernel on large graphs (test hook spmv_pipe = 2)")
     ap.add_argument("--comm", choices=["rccl", "shm"], default="rccl",
                     help="shm = rehearsal on ONE GPU: gloo process group + host-staged shared-memory communicator, all ranks on cuda:0")
     args = ap.parse_args()
@@ -137,6 +139,8 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP backend has no CPU path", file=sys.stderr)
         sys.exit(3)
+    if args.k3 == "pipelined":
+        P.set_knob("spmv_pipe", 2)
     rehearsal = args.comm == "shm"
     if rehearsal:
         local_rank = 0  # every rank shares cuda:0 (RCCL would refuse duplicate devices)

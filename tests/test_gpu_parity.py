@@ -560,22 +560,29 @@ def test_direct_solve_other_options_and_reproducibility(pgo, oracle):
 
 
 def test_product_kernels_agree(pgo, oracle):
-    """K3 has two product kernels -- the software-pipelined k_spmv_p (plain tiles) and k_spmv_t (every other case) -- and
-    small graphs take the fused-direction-update loop (k_spmv_t MODE 5): the same product / the same solve from each"""
-    g = pgo.synth_manhattan(60000, 4.0, 0.10, 3)
+    """K3 has three product kernels -- k_spmv_1 (plain tiles, one per workgroup: large graphs), the software-pipelined
+    k_spmv_p (plain tiles, persistent workgroups) and k_spmv_t (every other case) -- and small graphs take the
+    fused-direction-update loop (k_spmv_t MODE 5): the same product / the same solve from each"""
+    # 160k poses: more than 4096 row tiles, where the default is k_spmv_1 (one tile per workgroup); hook 2 keeps the pipelined
+    # k_spmv_p, hook 0 k_spmv_t
+    g = pgo.synth_manhattan(160000, 4.0, 0.10, 3)
     x = np.random.default_rng(9).standard_normal(3 * g.n_poses)
-    ys = {}
-    for pipe in ("1", "0"):
+    ys, its = {}, {}
+    for pipe in ("-1", "2", "0"):
         pgo.set_knob("spmv_pipe", int(pipe))
         try:
             s = pgo.Solver(g, pgo.Options(method=1, max_iters=2, pcg_rtol=0.1, pcg_max_iters=100))
         finally:
             pgo.set_knob("spmv_pipe", -1)
+        assert s.info().n_tiles > 4096
         s.lm_begin()
-        s.lm_step(1)
+        s.lm_step(2)
+        its[pipe] = [r["pcg_iters"] for r in s.iter_records()]
         ys[pipe] = s.spmv(x)
         s.close()
-    assert np.abs(ys["1"] - ys["0"]).max() < 1e-11 * np.abs(ys["0"]).max()
+    assert np.abs(ys["-1"] - ys["0"]).max() < 1e-11 * np.abs(ys["0"]).max()
+    assert np.abs(ys["2"] - ys["0"]).max() < 1e-11 * np.abs(ys["0"]).max()
+    assert its["-1"] == its["2"] == its["0"]          # the same PCG solves whichever kernel multiplies
     og = oracle_graph(oracle, g)
     # the fused loop against the three-kernel loop on a small graph: same iterates up to rounding
     gi = load(pgo, "INTEL", 50)

@@ -1003,6 +1003,72 @@ __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
   if (tid == 0) A.dot_part[blockIdx.x] = tot;
 }
 
+// ------------------------------------------------------------------- K3, one tile per workgroup
+// The same product once more, in the opposite style: NO software pipeline, (about) one tile per workgroup and as many
+// workgroups as tiles -- 31.8k at 1M poses -- so that the hardware's workgroup scheduler does the overlapping: eight short
+// workgroups per compute unit, each one dependent chain (descriptor -> column index -> block + gather -> row phase), a new one
+// starting whenever one retires.  Measured on the box where the pipelined k_spmv_p (1024 persistent workgroups) takes
+// 164-166 us: k_spmv_t with 2048 / 4096 / 8192 / 16384 / 31808 workgroups 188 / 179 / 173 / 167 / 154 us.  Plain tiles only
+// (<= 256 incidences, <= 85 rows); its 31.8k dot partials are summed by one k_finalize launch.
+template <int PGO_UNIT_ = 0>
+__global__ __launch_bounds__(WG) void k_spmv_1(SpmvArgs A) {
+  __shared__ double scr[2][3][WG];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  if (A.done && *A.done) return;
+  const int64_t n = A.n_loc;
+  const XcdRange xr = xcd_range(A.n_tiles);
+  double dot = 0.0;
+  int buf = 0;
+  for (int t = xr.begin; t < xr.end; t += xr.step) {
+    const int4 d = A.tile_desc[t];
+    const int r0 = d.x, nrows = d.y, q0 = d.z, nq = d.w;
+    const bool on = tid < nq, pv = tid < nrows * 3;
+    int col = 0;
+    if (on) col = ld_stream(A.inc_col + q0 + tid);
+    // row operands first (independent of the column index): row a of the diagonal block with D'D folded in, own direction
+    int a = 0, row = r0, lo = 0, hi = 0;
+    double h0 = 0.0, h1 = 0.0, h2 = 0.0, pr0 = 0.0, pr1 = 0.0, pr2 = 0.0;
+    if (pv) {
+      a = tid / nrows;
+      row = r0 + (tid - a * nrows);
+      lo = A.inc_ptr[row] - q0;
+      hi = A.inc_ptr[row + 1] - q0;
+      const int i0 = (a == 0) ? 0 : a, i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
+      const double* hdg = A.with_d2 ? A.hdd + ((int64_t)a * n + row) : A.hd + ((int64_t)(a == 0 ? 0 : (a == 1 ? 3 : 5)) * n + row);
+      const double dg = ld_stream(hdg);
+      const double o0 = (a == 0) ? 0.0 : ld_stream(A.hd + ((int64_t)i0 * n + row));
+      const double o1 = (a == 1) ? 0.0 : ld_stream(A.hd + ((int64_t)i1 * n + row));
+      const double o2 = (a == 2) ? 0.0 : ld_stream(A.hd + ((int64_t)i2 * n + row));
+      h0 = (a == 0) ? dg : o0;
+      h1 = (a == 1) ? dg : o1;
+      h2 = (a == 2) ? dg : o2;
+      gather3(A.p, (int64_t)A.lo + row, pr0, pr1, pr2);
+    }
+    if (on) {
+      double h[9], p0, p1, p2;
+      if (A.nt) hoff_load_nt(A.hoff, q0 + tid, h);
+      else hoff_load(A.hoff, q0 + tid, h);
+      gather3(A.p, (int64_t)col, p0, p1, p2);
+      scr[buf][0][tid] = h[0] * p0 + h[1] * p1 + h[2] * p2;
+      scr[buf][1][tid] = h[3] * p0 + h[4] * p1 + h[5] * p2;
+      scr[buf][2][tid] = h[6] * p0 + h[7] * p1 + h[8] * p2;
+    }
+    __syncthreads();
+    if (pv) {
+      double s = 0.0;
+      for (int j = lo; j < hi; ++j) s += scr[buf][a][j];
+      const double pa = (a == 0) ? pr0 : (a == 1 ? pr1 : pr2);
+      s += h0 * pr0 + h1 * pr1 + h2 * pr2;
+      st_stream(A.y + (3 * (int64_t)row + a), s);
+      dot += pa * s;
+    }
+    buf ^= 1;
+  }
+  const double tot = block_sum_bcast(dot, red);
+  if (tid == 0) A.dot_part[blockIdx.x] = tot;
+}
+
 // The blocks whose column lives on another rank (a few % of a shard's incidences, listed per row at create): after the
 // halo exchange, y_row += sum H_rc p_c and the matching part of p . A p.  One thread per row that has such blocks.
 struct RemoteArgs {
@@ -1162,6 +1228,28 @@ __global__ __launch_bounds__(WG) void k_finalize(FinArgs A) {
     }
     if (threadIdx.x == 0) A.out[k] = v;
   }
+}
+
+// n partials -> gridDim.x partials (fixed order): workgroup b sums its contiguous share, every thread a handful of elements
+// requested together.  Between k_spmv_1 (one dot partial per tile: 31.8k at 1M poses) and the update kernel, whose workgroups
+// each re-sum the partials they are given: one workgroup summing 31.8k values alone took ~15 us of every PCG iteration.
+template <int PGO_UNIT_ = 0>
+__global__ __launch_bounds__(WG) void k_fold_partials(const double* __restrict__ in, int n, double* __restrict__ out,
+                                                      const int32_t* __restrict__ done) {
+  __shared__ double red[8];
+  if (done && *done) return;
+  const int chunk = (n + gridDim.x - 1) / gridDim.x;
+  const int b0 = blockIdx.x * chunk, b1 = min(n, b0 + chunk);
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = b0 + threadIdx.x + k * WG;
+    v[k] = i < b1 ? in[i] : 0.0;
+  }
+  double s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  for (int i = b0 + threadIdx.x + 8 * WG; i < b1; i += WG) s += in[i];
+  s = block_sum_bcast(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 // ------------------------------------------------------------------- K5

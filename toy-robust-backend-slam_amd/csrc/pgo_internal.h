@@ -70,7 +70,10 @@ struct ShardStructure {
   std::vector<int64_t> halo_send_off, halo_recv_off;   // world + 1 each, in rows
 };
 
-constexpr int TILE_INC = 256;
+#ifndef PGO_TILE_INC
+#define PGO_TILE_INC 256   // (experiment builds may lower it: smaller tiles, more workgroups)
+#endif
+constexpr int TILE_INC = PGO_TILE_INC;
 
 inline int32_t rows_per_rank(int32_t n_poses, int world, int row_align) {
   const int64_t rpr = ((int64_t)n_poses + world - 1) / world;

@@ -142,7 +142,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   if (const char* fe = PGO_EXP_ENV("PGO_FLAT_GRID")) g_flat = std::min(g_flat, std::max(8, atoi(fe)));
   g_spmv = up8(std::min(std::max(1, S.n_tiles()), 2048));
   g_asm = up8(std::min(std::max(1, S.n_tiles()), 1 << 20));
-  part_cap = std::max(g_edge, 2048) + 8 + 512;   // (+ the coarse level's dot partials behind the one-level r.z partials)
+  part_cap = std::max(std::max(g_edge, 2048), up8(std::max(1, S.n_tiles()))) + 8 + 512;   // (k_spmv_1: one dot partial per tile)   // (+ the coarse level's dot partials behind the one-level r.z partials)
   for (int k = 0; k < N_PART; ++k) PGOC(dalloc(&part[k], part_cap));
 
   HIPC(hipMemcpyAsync(poses, poses_h, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -191,6 +191,13 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
         int per_cu = 4;
         if (const char* ge = PGO_EXP_ENV("PGO_SPMV_PIPE_WGS")) per_cu = std::max(1, atoi(ge));
         g_spmv = ((std::min(std::max(1, S.n_tiles()), 256 * per_cu) + 7) / 8) * 8;
+        // Large graphs: one tile per workgroup (k_spmv_1) -- 154 us against the pipelined form's 164-166 us at 1M poses; test
+        // hook "spmv_pipe" = 2 keeps k_spmv_p there.  Up to 4096 tiles the persistent forms stay (fewer partials, no
+        // k_finalize launch in a latency-bound iteration).
+        if (S.n_tiles() > 4096 && knob("spmv_pipe") != 2 && up8(S.n_tiles()) + 8 + 512 <= part_cap) {
+          spmv_one_tile = true;
+          g_spmv = up8(S.n_tiles());
+        }
       }
     }
     PGOC(dalloc(&tile_desc, (int64_t)desc.size()));

@@ -120,6 +120,7 @@ struct pgo_handle {
   int32_t *inc_ptr = nullptr, *inc_edge = nullptr, *inc_col = nullptr, *tile_row = nullptr;
   uint8_t* inc_rowoff = nullptr;
   int4* tile_desc = nullptr;
+  bool spmv_one_tile = false;   // the plain-tile product kernel as k_spmv_1: one tile per workgroup, as many workgroups as tiles
   bool spmv_pipe = false;   // software-pipelined K3 (k_spmv_p): when no tile is a chunked heavy row or has > 85 rows
   int64_t inc_stride = 0;
   // normal equations

@@ -82,7 +82,8 @@ int pgo_handle::spmv_enqueue(const double* p, double* yout, double* dot_part, in
     case 3: hipLaunchKernelGGL(dev::k_spmv_t<3>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
 #endif
     default:
-      if (spmv_pipe) hipLaunchKernelGGL(dev::k_spmv_p<dev::PS>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+      if (spmv_pipe && spmv_one_tile) hipLaunchKernelGGL(dev::k_spmv_1<>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+      else if (spmv_pipe) hipLaunchKernelGGL(dev::k_spmv_p<dev::PS>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
       else hipLaunchKernelGGL(dev::k_spmv_t<0>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
   }
   return check_launch("k_spmv");

@@ -182,9 +182,16 @@ int pgo_handle::pcg(int* iters, double* rel) {
       Vi.fused = 1;
     } else if (overlap) PGOC(spmv_with_halo(p_full, ap, part[0], &st->done, &n_sp));  // p reaches the peers inside
     else PGOC(spmv_enqueue(p_full, ap, part[0], 1, &st->done));
-    const double* pap = multi ? scal + 6 : part[0];
-    const int n_pap = multi ? 1 : n_sp;
+    // p.Ap: every workgroup of the update kernel re-sums the product's partials itself -- up to 2048 of them; more (k_spmv_1:
+    // one per tile) are folded to 16 first (k_fold_partials); several ranks: k_finalize + all-reduce
+    const bool fold_pap = !multi && n_sp > 2048;
+    const double* pap = multi ? scal + 6 : (fold_pap ? part[3] : part[0]);
+    const int n_pap = multi ? 1 : (fold_pap ? 16 : n_sp);
     if (multi) PGOC(reduce_to_scal({{part[0], n_sp, 0}}, 6));
+    else if (fold_pap) {
+      hipLaunchKernelGGL(dev::k_fold_partials<>, dim3(16), dim3(dev::WG), 0, stream, (const double*)part[0], n_sp, part[3], (const int32_t*)&st->done);
+      PGOC(check_launch("k_fold_partials"));
+    }
     if (chained) launch_cg_update1_chain(Vi, par, pap, n_pap, part[1], part[2]);
     else if (grouped) hipLaunchKernelGGL(dev::k_cg_update1_g<>, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, GP, par, pap, n_pap, part[1], part[2]);
     else hipLaunchKernelGGL(dev::k_cg_update1<>, dim3(g_u1), dim3(dev::WG), 0, stream, Vi, par, pap, n_pap, part[1], part[2]);
