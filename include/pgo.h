@@ -398,7 +398,8 @@ int pgo_debug_normal_eq(pgo_t* h, double* g_or_null, double* hdiag_or_null);    
  * PGO_FORCE_COLLECTIVES (1 = issue the collectives at world == 1 too, where they are identities) and
  * PGO_GRAPH_COLLECTIVES (0 = never capture collectives into the PCG hipGraph, 1 = all-reduce / all-gather, 2 = also the
  * point-to-point exchange), and never lets the environment override a pgo_options field.
- *   "spmv_pipe"          0 = K3 as k_spmv_t instead of the software-pipelined k_spmv_p (the two must agree)
+ *   "spmv_pipe"          0 = K3 as k_spmv_t; 2 = K3 as the software-pipelined k_spmv_p even where k_spmv_1 (one row tile
+ *                        per workgroup, graphs with more than 4096 tiles) is the default (all three must agree)
  *   "fused_p"            0 = small graphs keep the three-launch PCG loop (no direction update inside the SpMV)
  *   "direct_fail_at"     k = the direct solve of LM iteration k returns NaNs (exercises the PCG redo)
  *   "direct_setup_fail"  1 = setting up the direct solver fails with PGO_ERR_NOMEM after its first allocations
