@@ -171,6 +171,23 @@ def test_single_reduction_pcg_matches_two_reduction_loop(tmp_path, world, halo, 
     assert np.abs(one_poses[0] - two_poses[0]).max() < 1e-5 and np.abs(one_poses[0] - ref_poses[0]).max() < 1e-5
 
 
+def test_sharded_solve_with_one_tile_product_kernel(tmp_path):
+    """shards of more than 4096 row tiles: every rank multiplies with k_spmv_1 (one tile per workgroup, one dot partial
+    per tile) and reduce_to_scal folds those partials (k_fold_partials) in front of k_finalize / the all-reduce -- in the
+    one-reduction loop (default) and in the two-reduction loop; same LM history as one rank"""
+    base = dict(graph="synth", n_poses=300001, seed=21, options=dict(method=1, max_iters=3, pcg_rtol=0.1, pcg_max_iters=500))
+    ref, ref_poses = run(1, base, tmp_path, tag="ref")
+    for knobs, tag in ((None, "one"), (dict(single_reduction=0), "two")):
+        res, poses = run(2, dict(base, knobs=knobs), tmp_path, tag=tag)
+        for r in range(2):
+            assert res[r]["info"]["n_tiles"] > 4096 and res[r]["info"]["pcg_single_reduction"] == (knobs is None)
+            np.testing.assert_array_equal(poses[r], poses[0])
+            for a, b in zip(res[r]["records"], ref[0]["records"]):
+                assert a["step_ok"] == b["step_ok"] and a["cost"] == pytest.approx(b["cost"], rel=1e-8)
+                assert abs(a["pcg_iters"] - b["pcg_iters"]) <= 2
+        assert np.abs(poses[0] - ref_poses[0]).max() < 1e-5
+
+
 def test_single_reduction_pcg_in_a_captured_graph_with_rccl(tmp_path):
     """world == 1 through RCCL with the collectives forced on: the one-reduction loop -- kernels, all-gather, all-reduce --
     is captured into the PCG hipGraph and replayed; same result as the plain single-rank solve.  The exact mode

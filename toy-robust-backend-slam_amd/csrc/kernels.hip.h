@@ -188,7 +188,16 @@ __device__ __forceinline__ double block_max_bcast(double v, double* sh) {
 // everywhere, no atomics, bitwise reproducible.
 __device__ __forceinline__ double sum_partials_bcast(const double* __restrict__ part, int n, double* sh) {
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += WG) v += part[i];
+  int i = threadIdx.x;
+  // (eight loads in flight per thread; the additions in the order of the plain loop)
+  for (; i + 7 * WG < n; i += 8 * WG) {
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = part[i + k * WG];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += a[k];
+  }
+  for (; i < n; i += WG) v += part[i];
   return block_sum_bcast(v, sh);
 }
 
@@ -1004,15 +1013,15 @@ __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
 }
 
 // ------------------------------------------------------------------- K3, one tile per workgroup
-// The same product once more, in the opposite style: NO software pipeline, (about) one tile per workgroup and as many
-// workgroups as tiles -- 31.8k at 1M poses -- so that the hardware's workgroup scheduler does the overlapping: eight short
-// workgroups per compute unit, each one dependent chain (descriptor -> column index -> block + gather -> row phase), a new one
-// starting whenever one retires.  Measured on the box where the pipelined k_spmv_p (1024 persistent workgroups) takes
-// 164-166 us: k_spmv_t with 2048 / 4096 / 8192 / 16384 / 31808 workgroups 188 / 179 / 173 / 167 / 154 us.  Plain tiles only
-// (<= 256 incidences, <= 85 rows); its 31.8k dot partials are summed by one k_finalize launch.
-template <int PGO_UNIT_ = 0>
-__global__ __launch_bounds__(WG) void k_spmv_1(SpmvArgs A) {
-  __shared__ double scr[2][3][WG];
+// The same product once more, in the opposite style: NO software pipeline, one tile per workgroup and as many workgroups
+// as tiles -- 31.8k at 1M poses -- so that the hardware's workgroup scheduler does the overlapping: short workgroups, each
+// one dependent chain (descriptor -> column index -> block + gather -> row phase), a new one starting whenever one
+// retires.  Measured on the box where the pipelined k_spmv_p (1024 persistent workgroups) takes 164-166 us: k_spmv_t with
+// 2048 / 4096 / 8192 / 16384 / 31808 workgroups 188 / 179 / 173 / 167 / 154 us, this kernel 151 us.  Plain tiles only
+// (<= TW incidences, <= TW / 3 rows, TW threads); its dot partials -- one per tile -- are folded by k_fold_partials.
+template <int TW = WG>
+__global__ __launch_bounds__(TW) void k_spmv_1(SpmvArgs A) {
+  __shared__ double scr[2][3][TW];
   __shared__ double red[8];
   const int tid = threadIdx.x;
   if (A.done && *A.done) return;
@@ -1065,8 +1074,17 @@ __global__ __launch_bounds__(WG) void k_spmv_1(SpmvArgs A) {
     }
     buf ^= 1;
   }
-  const double tot = block_sum_bcast(dot, red);
-  if (tid == 0) A.dot_part[blockIdx.x] = tot;
+  dot = wave_sum(dot);
+  if (TW > 64) {
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    if (tid == 0) {
+      dot = red[0];
+#pragma unroll
+      for (int w = 1; w < TW / 64; ++w) dot += red[w];
+    }
+  }
+  if (tid == 0) A.dot_part[blockIdx.x] = dot;
 }
 
 // The blocks whose column lives on another rank (a few % of a shard's incidences, listed per row at create): after the

@@ -120,6 +120,8 @@ struct pgo_handle {
   int32_t *inc_ptr = nullptr, *inc_edge = nullptr, *inc_col = nullptr, *tile_row = nullptr;
   uint8_t* inc_rowoff = nullptr;
   int4* tile_desc = nullptr;
+  int4* k3_desc = nullptr;      // (experiment builds: k_spmv_1's own, finer tile list)
+  int k3_tw = 0, n_k3 = 0;
   bool spmv_one_tile = false;   // the plain-tile product kernel as k_spmv_1: one tile per workgroup, as many workgroups as tiles
   bool spmv_pipe = false;   // software-pipelined K3 (k_spmv_p): when no tile is a chunked heavy row or has > 85 rows
   int64_t inc_stride = 0;
@@ -145,6 +147,7 @@ struct pgo_handle {
   dev::CgState* h_st = nullptr;  // pinned
   // reductions
   double* part[N_PART] = {nullptr};
+  double* fold_buf = nullptr;   // 6 x 16: reduce_to_scal's intermediate for partial arrays too long for one workgroup
   int part_cap = 0;
   double* scal = nullptr;
   double* h_scal = nullptr;  // pinned

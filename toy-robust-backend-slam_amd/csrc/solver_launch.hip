@@ -11,6 +11,13 @@ int pgo_handle::reduce_to_scal(std::initializer_list<PartRef> parts, int first, 
     F.part[k] = pr.p;
     F.n[k] = pr.n;
     F.is_max[k] = pr.is_max;
+    if (!pr.is_max && pr.n > 4096 && fold_buf) {
+      // k_finalize is ONE workgroup: tens of thousands of partials (k_spmv_1: one per tile) go through 16 workgroups first
+      hipLaunchKernelGGL(dev::k_fold_partials<>, dim3(16), dim3(dev::WG), 0, stream, pr.p, pr.n, fold_buf + 16 * k, (const int32_t*)nullptr);
+      PGOC(check_launch("k_fold_partials"));
+      F.part[k] = fold_buf + 16 * k;
+      F.n[k] = 16;
+    }
     ++k;
   }
   F.count = k;
@@ -82,6 +89,14 @@ int pgo_handle::spmv_enqueue(const double* p, double* yout, double* dot_part, in
     case 3: hipLaunchKernelGGL(dev::k_spmv_t<3>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
 #endif
     default:
+#ifdef PGO_EXPERIMENTS
+      if (spmv_pipe && spmv_one_tile && k3_tw) {
+        A.tile_desc = k3_desc;
+        A.n_tiles = n_k3;
+        if (k3_tw == 64) hipLaunchKernelGGL(dev::k_spmv_1<64>, dim3(g_spmv), dim3(64), 0, stream, A);
+        else hipLaunchKernelGGL(dev::k_spmv_1<128>, dim3(g_spmv), dim3(128), 0, stream, A);
+      } else
+#endif
       if (spmv_pipe && spmv_one_tile) hipLaunchKernelGGL(dev::k_spmv_1<>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
       else if (spmv_pipe) hipLaunchKernelGGL(dev::k_spmv_p<dev::PS>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
       else hipLaunchKernelGGL(dev::k_spmv_t<0>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
