@@ -405,6 +405,8 @@ int pgo_debug_normal_eq(pgo_t* h, double* g_or_null, double* hdiag_or_null);    
  *   "direct_setup_fail"  1 = setting up the direct solver fails with PGO_ERR_NOMEM after its first allocations
  *   "single_reduction"   1 / 0 = force the one-reduction (Chronopoulos-Gear) PCG loop on / off (default: on for
  *                        world > 1 in the inexact mode, pcg_rtol >= 1e-6)
+ *   "verify_residual"    1 = pcg_rel_residual of the iteration records is the TRUE |b - A y| / |b| of each PCG solve (one
+ *                        more product per solve) instead of the recurrence residual the loop stopped on
  * Unknown name: PGO_ERR_INVALID_ARG.                                                                              */
 int pgo_debug_set_knob(const char* name, long long value);                        /* [host] */
 /* sharding plan of a graph over `world` ranks: for rank r, rows [lo, hi) and the

@@ -2814,6 +2814,26 @@ __global__ void k_scatter_owned(int n_loc, int lo, const double* __restrict__ sr
   }
 }
 
+// |b - A y|^2 and |b|^2 as partials (test hook "verify_residual": the TRUE residual of a finished PCG solve next to the
+// recurrence residual the loop stopped on)
+template <int PGO_UNIT_ = 0>
+__global__ __launch_bounds__(WG) void k_residual_norm(int64_t n3, const double* __restrict__ b, const double* __restrict__ ay,
+                                                      double* __restrict__ part_rr, double* __restrict__ part_bb) {
+  __shared__ double red[8];
+  double rr = 0.0, bb = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n3; i += (int64_t)gridDim.x * WG) {
+    const double d = b[i] - ay[i];
+    rr += d * d;
+    bb += b[i] * b[i];
+  }
+  rr = block_sum_bcast(rr, red);
+  bb = block_sum_bcast(bb, red);
+  if (threadIdx.x == 0) {
+    part_rr[blockIdx.x] = rr;
+    part_bb[blockIdx.x] = bb;
+  }
+}
+
 // halo exchange helpers: pack rows of the gather vector into a contiguous buffer / scatter them back
 template <int PGO_UNIT_ = 0>   // (a template so that only the translation units that launch it carry it)
 __global__ void k_pack_rows(int64_t n_rows, const int32_t* __restrict__ rows, const double* __restrict__ src,

@@ -198,7 +198,9 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
         // Large graphs: one tile per workgroup (k_spmv_1) -- 154 us against the pipelined form's 164-166 us at 1M poses; test
         // hook "spmv_pipe" = 2 keeps k_spmv_p there.  Up to 4096 tiles the persistent forms stay (fewer partials, no
         // k_finalize launch in a latency-bound iteration).
-        if (S.n_tiles() > 4096 && knob("spmv_pipe") != 2 && up8(S.n_tiles()) + 8 + 512 <= part_cap) {
+        int one_tile_min = 4096;
+        if (const char* om = PGO_EXP_ENV("PGO_ONE_TILE_MIN")) one_tile_min = atoi(om);
+        if (S.n_tiles() > one_tile_min && knob("spmv_pipe") != 2 && up8(S.n_tiles()) + 8 + 512 <= part_cap) {
           spmv_one_tile = true;
           g_spmv = up8(S.n_tiles());
 #ifdef PGO_EXPERIMENTS
@@ -402,6 +404,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     use_sr = chain_len > 0 && chain_chunk > 0 && !solo && !fused_p && !batch_mode && NL > 0 && opt.pcg_rtol >= 1e-6 &&
              (kn == 1 || (kn != 0 && (world > 1 || force_collectives)));
     if (use_sr) PGOC(dalloc(&sr_s, 3 * NL));
+    verify_residual = knob("verify_residual") == 1;
   }
   if (!fixed_mask_h.empty()) {
     PGOC(dalloc(&fixed_mask, (int64_t)fixed_mask_h.size()));

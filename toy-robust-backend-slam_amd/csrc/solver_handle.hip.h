@@ -142,6 +142,7 @@ struct pgo_handle {
   int coarse_solve(double* dot_part, const int32_t* done);   // e_c = (P'(H + D'D)P)^-1 P' r  (+ partials of r_c . e_c)
   // single-reduction PCG loop (k_cg_sr_*: one all-reduce per iteration; several ranks, inexact mode, chain preconditioner)
   bool use_sr = false;
+  bool verify_residual = false;   // test hook: pcg() reports the true residual of its solution
   double* sr_s = nullptr;   // s = A p, carried by recurrence
   dev::CgState* st = nullptr;
   dev::CgState* h_st = nullptr;  // pinned

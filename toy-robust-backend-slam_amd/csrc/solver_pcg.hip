@@ -298,6 +298,21 @@ int pgo_handle::pcg(int* iters, double* rel) {
   last_pcg_iters = h_st->iters;
   *iters = h_st->iters;
   *rel = (h_st->bb > 0.0) ? std::sqrt(h_st->rr / h_st->bb) : 0.0;
+  if (verify_residual) {
+    // test hook: report |b - A y| / |b| of the solution instead of the recurrence residual the loop stopped on (one more
+    // product; the recurrences of either loop drift from it on ill-conditioned systems)
+    hipLaunchKernelGGL(dev::k_scatter_owned<>, dim3(g_flat), dim3(dev::WG), 0, stream, (int)S.n_loc, (int)S.lo, (const double*)V.y, p_full);
+    PGOC(check_launch("k_scatter_owned"));
+    PGOC(share_gather_vector(p_full));
+    PGOC(spmv_enqueue(p_full, ap, part[0], 1, nullptr));
+    hipLaunchKernelGGL(dev::k_residual_norm<>, dim3(g_flat), dim3(dev::WG), 0, stream, (int64_t)3 * S.n_loc, (const double*)gs, (const double*)ap, part[1], part[2]);
+    PGOC(check_launch("k_residual_norm"));
+    PGOC(reduce_to_scal({{part[1], g_flat, 0}, {part[2], g_flat, 0}}, 4));
+    double h2[2] = {0.0, 0.0};
+    HIPC(hipMemcpyAsync(h2, scal + 4, sizeof h2, hipMemcpyDeviceToHost, stream));
+    PGOC(sync());
+    *rel = (h2[1] > 0.0) ? std::sqrt(h2[0] / h2[1]) : 0.0;
+  }
   return PGO_OK;
 }
 
