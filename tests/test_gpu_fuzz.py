@@ -194,6 +194,54 @@ def test_coarse_level_and_single_reduction_loop_on_arbitrary_graphs(pgo, case, a
         a.close(); b.close()
 
 
+@st.composite
+def graph_bundles(draw):
+    k = draw(st.integers(1, 9))
+    recipes = []
+    for _ in range(k):
+        n = draw(st.sampled_from([2, 3, 7, 64, 65, 85, 86, 200, 255, 256, 257, 300]) | st.integers(2, 400))
+        recipes.append((n, draw(st.integers(0, 2 ** 31 - 1)), draw(st.sampled_from([1.0, 1.0, 0.7])), draw(st.integers(0, 2 * n)),
+                        draw(st.booleans()) and n > 8, draw(st.integers(0, 3))))
+    method = draw(st.sampled_from([0, 1]))
+    fixed = draw(st.sampled_from([0, 0, -1]))
+    note("graph_bundles recipe: %r method=%d fixed=%d" % (recipes, method, fixed))
+    return recipes, method, fixed
+
+
+@settings(**dict(SETTINGS, max_examples=FUZZ_N or 15))
+@given(graph_bundles())
+def test_batched_handle_on_arbitrary_bundles(pgo, bundle):
+    """pgo_batch_*: bundles of 1-9 arbitrary small graphs (row counts around the tile limits 85 / 256, edge-less poses,
+    hubs, duplicate pairs, with and without a constant pose) in ONE handle -- every problem must come out as its own
+    single-handle PCG solve does: same accept / reject history, cost to 1e-9 of the initial cost, poses to 1e-7"""
+    recipes, method, fixed = bundle
+    graphs = []
+    for rc in recipes:
+        poses, ia, ib, meas, kind = make_graph(*rc)
+        if len(ia) == 0:
+            return
+        graphs.append(pgo.Graph.from_arrays(poses, ia, ib, meas, kind))
+    opt = dict(method=method, fixed_pose=fixed, max_iters=3, pcg_rtol=1e-12, pcg_max_iters=100000)
+    max_deg = max(int(np.bincount(np.concatenate([np.array(g.ia), np.array(g.ib)])).max()) for g in graphs)
+    try:
+        b = pgo.Batch(graphs, pgo.Options(**opt))
+    except pgo.PgoError as e:        # the one documented refusal: a pose with more incident edges than a row tile holds
+        assert e.status == -8 and max_deg > 256, str(e)
+        return
+    assert max_deg <= 256
+    sb = b.solve()
+    for k, g in enumerate(graphs):
+        s = pgo.Solver(g, pgo.Options(linear_solver=1, pcg_coarse_poses=0, **opt))
+        ss = s.solve()
+        c0 = max(ss.initial_cost, 1e-30)
+        assert sb[k].initial_cost == pytest.approx(ss.initial_cost, rel=1e-12, abs=1e-300)
+        assert [r["step_ok"] for r in b.iter_records(k)] == [r["step_ok"] for r in s.iter_records()], k
+        assert abs(sb[k].final_cost - ss.final_cost) <= 1e-9 * c0, k
+        assert np.abs(b.poses(k) - s.poses()).max() < 1e-7 * max(1.0, np.abs(s.poses()).max()), k
+        s.close()
+    b.close()
+
+
 def test_mit_distance_from_the_fixture_is_the_conditioning(pgo):
     """MIT METHOD 1 runs at a trust-region radius of ~3e11, where the LM systems are so ill-conditioned that ANY two accurate
     solves end ~1e-6 apart after 50 iterations: two independent HIP solves -- PCG to 1e-13 and the direct chain + low-rank
