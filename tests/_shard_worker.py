@@ -14,6 +14,10 @@ def main():
     rank, world = cfg["rank"], cfg["world"]
     if cfg["graph"] == "synth":
         g = P.synth_manhattan(cfg["n_poses"], 4.0, 0.10, cfg["seed"])
+    elif cfg["graph"] == "recipe":      # an arbitrary small graph of tests/test_gpu_fuzz.py
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_fuzz import make_graph
+        g = P.Graph.from_arrays(*make_graph(*cfg["recipe"]))
     else:
         g = P.ReadG2O(os.path.join(ROOT, "tests", "golden", "data", cfg["graph"] + ".g2o"))
         if cfg.get("outliers"):

@@ -24,6 +24,8 @@
 #include "comm.h"
 #include "pgo_internal.h"
 
+long long knob(const char* name);   // test hooks (solver_abi.hip)
+
 namespace pgo {
 
 // ------------------------------------------------------------------ RCCL
@@ -81,6 +83,8 @@ struct ShmComm final : pgo_comm {
     if (rank == 0) shm_unlink(name.c_str());
   }
   int barrier() {
+    const long long kt = knob("shm_timeout_s");       // (test hook: campaigns over many small cases shorten the wait for a dead peer)
+    const long long timeout_s = kt > 0 ? kt : 120;
     const int gen = hdr->generation.load(std::memory_order_acquire);
     if (hdr->arrived.fetch_add(1, std::memory_order_acq_rel) == world - 1) {
       hdr->arrived.store(0, std::memory_order_relaxed);
@@ -92,7 +96,7 @@ struct ShmComm final : pgo_comm {
     while (hdr->generation.load(std::memory_order_acquire) == gen) {
       if (++spins > 256) {
         std::this_thread::sleep_for(std::chrono::microseconds(20));
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s))
           return fail(PGO_ERR_COMM, "shm barrier timeout (a peer died?)");
       }
     }

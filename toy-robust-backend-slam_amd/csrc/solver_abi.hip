@@ -8,7 +8,7 @@ struct Knob {
   const char* name;
   std::atomic<long long> value;
 };
-Knob g_knobs[] = {{"spmv_pipe", {-1}}, {"fused_p", {-1}}, {"direct_fail_at", {-1}}, {"direct_setup_fail", {-1}}, {"single_reduction", {-1}}, {"verify_residual", {-1}}};
+Knob g_knobs[] = {{"spmv_pipe", {-1}}, {"fused_p", {-1}}, {"direct_fail_at", {-1}}, {"direct_setup_fail", {-1}}, {"single_reduction", {-1}}, {"verify_residual", {-1}}, {"shm_timeout_s", {-1}}};
 }  // namespace
 long long knob(const char* name) {
   for (Knob& k : g_knobs)

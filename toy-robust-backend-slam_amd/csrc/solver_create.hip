@@ -299,7 +299,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   } else {
     grp_B = 1;
   }
-  if (chain_len && NL > 0) {
+  if (chain_len) {   // (also on a rank that owns no rows: every rank must resolve to the same PCG loop and the same collectives)
     chain_pad = (int)(((NL + dev::CHAIN_TILE - 1) / dev::CHAIN_TILE) * dev::CHAIN_TILE);
     PGOC(dalloc(&chain_c, (int64_t)dev::CHAIN_REC * NL));   // zero-filled: rows without a block (i, i-1) keep C = 0
     {
@@ -322,7 +322,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     // the padding rows of the factor planes are never written: they must read as 0
     HIPC(hipMemsetAsync(chain_w, 0, (size_t)9 * chain_pad * sizeof(double), stream));
     HIPC(hipMemsetAsync(chain_s, 0, (size_t)6 * chain_pad * sizeof(double), stream));
-    g_chain = (int)std::min<int64_t>((NL + 4 * dev::CHAIN_TILE - 1) / (4 * dev::CHAIN_TILE), 2048);
+    g_chain = (int)std::max<int64_t>(1, std::min<int64_t>((NL + 4 * dev::CHAIN_TILE - 1) / (4 * dev::CHAIN_TILE), 2048));
     // apply kernel: the lean form (one DPP-shift recurrence step per lane of a segment), 2 poses per lane for segments of
     // <= 64 poses, 4 for longer ones (INTEL, chain-256: 20 us per apply in the scan form -- five 256-row tiles, latency-
     // bound -- of a 30 us PCG iteration); PGO_CHAIN_KERNEL = scan | lean2 | lean4 overrides (experiments)
@@ -354,10 +354,8 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
       // iteration at 1M poses (same box, 3 interleaved repetitions)
       int cap = 512;
       if (const char* ce = PGO_EXP_ENV("PGO_CHAIN_GRID")) cap = std::max(8, atoi(ce));
-      g_chain = (int)std::min<int64_t>((n_wt + chain_nw - 1) / chain_nw, chain_nw == 1 ? 2048 : cap);
+      g_chain = (int)std::max<int64_t>(1, std::min<int64_t>((n_wt + chain_nw - 1) / chain_nw, chain_nw == 1 ? 2048 : cap));
     }
-  } else {
-    chain_len = 0;
   }
   // One-workgroup PCG (solo.hip.h): a single rank, a chain or 3x3 block-Jacobi preconditioner, no chunked heavy row.
   {
@@ -401,7 +399,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
     // and only in the inexact mode (pcg_rtol >= 1e-6: the recurrence for A p drifts over the thousands of iterations of
     // the exact mode); needs the lean chain apply.  Test hook "single_reduction": 1 = also on one rank, 0 = never.
     const long long kn = knob("single_reduction");
-    use_sr = chain_len > 0 && chain_chunk > 0 && !solo && !fused_p && !batch_mode && NL > 0 && opt.pcg_rtol >= 1e-6 &&
+    use_sr = chain_len > 0 && chain_chunk > 0 && !solo && !fused_p && !batch_mode && opt.pcg_rtol >= 1e-6 &&
              (kn == 1 || (kn != 0 && (world > 1 || force_collectives)));
     if (use_sr) PGOC(dalloc(&sr_s, 3 * NL));
     verify_residual = knob("verify_residual") == 1;

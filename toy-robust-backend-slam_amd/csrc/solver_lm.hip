@@ -232,8 +232,8 @@ int pgo_handle::lm_iteration_tail(bool* stop, pgo_iter_record& R, double it0, do
     }
     if (true_residual) {
       PGOC(spmv_enqueue(p_full, ap, part[0], 1, nullptr));
-      hipLaunchKernelGGL(dev::k_dlr_resid<>, dim3((3 * S.n_loc + 255) / 256), dim3(256), 0, stream, (int64_t)3 * S.n_loc, (const double*)gs,
-                         (const double*)ap, r);
+      hipLaunchKernelGGL(dev::k_dlr_resid<>, dim3(std::max<int64_t>(1, (3 * S.n_loc + 255) / 256)), dim3(256), 0, stream, (int64_t)3 * S.n_loc,
+                         (const double*)gs, (const double*)ap, r);   // (at least one workgroup: a rank may own no rows)
       PGOC(check_launch("k_dlr_resid"));
     }
     // y.(H y) = y.b - y.r - y.(D y) from the residual (no further product by H): part[1] = y.b, part[0] = y.r, part[5] = y.(D y)

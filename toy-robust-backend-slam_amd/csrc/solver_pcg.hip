@@ -347,6 +347,7 @@ int pgo_handle::factor_chain() {
   // were measured SLOWER -- 233 us against 123 us: the same 128-byte-per-lane record loads then take four times as many
   // wave instructions through the address coalescer, and 174 instead of 122 MB are written.
   const int spw = 64;
+  if (n_seg == 0) return PGO_OK;   // a rank that owns no rows
   if ((chain_chunk ? chain_chunk : dev::CHAIN_CHUNK) == 2)
     hipLaunchKernelGGL(dev::k_chain_factor<2>, dim3((n_seg + spw - 1) / spw), dim3(spw), 0, stream, (const double*)chain_c, S.n_loc, chain_pad,
                        chain_len, chain_w, chain_s);
