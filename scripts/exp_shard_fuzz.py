@@ -13,7 +13,7 @@ for case in range(n_cases):
     n = int(rng.choice([3, 9, 63, 64, 65, 130, 257, 500, 1500]))
     recipe = [n, int(rng.integers(1 << 30)), float(rng.choice([1.0, 1.0, 0.6])), int(rng.integers(0, 2 * n)), bool(rng.integers(2)) and n > 8, int(rng.integers(0, 3))]
     world = int(rng.choice([2, 3, 4]))
-    opts = dict(method=int(rng.choice([0, 1])), fixed_pose=int(rng.choice([0, -1])), max_iters=3, pcg_rtol=float(rng.choice([1e-12, 1e-3])), pcg_max_iters=100000,
+    opts = dict(method=int(rng.choice([0, 1, 2])), fixed_pose=int(rng.choice([0, -1])), max_iters=3, pcg_rtol=float(rng.choice([1e-12, 1e-3])), pcg_max_iters=100000,
                 linear_solver=1, halo_exchange=int(rng.choice([0, 1])), pcg_chain_len=int(rng.choice([-1, 8, 64, 0])))
     cfg = dict(graph="recipe", recipe=recipe, options=opts, knobs=dict(shm_timeout_s=15))
     tag = "c%d" % case
