@@ -29,7 +29,7 @@ def short(name):
     n = name
     for k in ("k_edge_eval<true", "k_edge_eval<false", "k_edge_evalILb1", "k_edge_evalILb0", "k_edge_chi2", "k_assemble", "k_spmv",
               "k_cg_update1_cl", "k_cg_update1_c", "k_cg_update1_g", "k_cg_update1", "k_cg_update2", "k_cg_init_fin", "k_cg_init_cl", "k_cg_init_c", "k_cg_init_g", "k_cg_init",
-              "k_chain_factor", "k_chain_extract", "k_prepare_groups", "k_prepare", "k_finalize", "k_dot",
+              "k_chain_factor", "k_chain_extract", "k_prepare_groups", "k_prepare", "k_fold_partials", "k_finalize", "k_dot",
               "k_candidate", "k_scatter_owned", "k_grad_max", "k_xnorm", "k_jacobi_scale", "k_flag_to_double", "k_fill"):
         if k in n:
             return {"k_edge_evalILb1": "k_edge_eval<true>", "k_edge_evalILb0": "k_edge_eval<false>",
