@@ -204,6 +204,11 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
           spmv_one_tile = true;
           g_spmv = up8(S.n_tiles());
 #ifdef PGO_EXPERIMENTS
+          // PGO_K3_NT = 2 | 4: that many tiles (and 256-thread groups) per workgroup, that many times fewer dot partials
+          if (const char* nt = getenv("PGO_K3_NT")) {
+            k3_nt = atoi(nt) == 4 ? 4 : (atoi(nt) == 2 ? 2 : 0);
+            if (k3_nt) g_spmv = up8((S.n_tiles() + k3_nt - 1) / k3_nt);
+          }
           // PGO_K3_TW = 64 | 128: k_spmv_1 on its own, finer tiles (<= TW incidences, TW threads per workgroup)
           if (const char* tw = getenv("PGO_K3_TW")) {
             const int TW = atoi(tw);

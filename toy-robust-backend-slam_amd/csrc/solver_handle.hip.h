@@ -121,7 +121,7 @@ struct pgo_handle {
   uint8_t* inc_rowoff = nullptr;
   int4* tile_desc = nullptr;
   int4* k3_desc = nullptr;      // (experiment builds: k_spmv_1's own, finer tile list)
-  int k3_tw = 0, n_k3 = 0;
+  int k3_tw = 0, n_k3 = 0, k3_nt = 0;
   bool spmv_one_tile = false;   // the plain-tile product kernel as k_spmv_1: one tile per workgroup, as many workgroups as tiles
   bool spmv_pipe = false;   // software-pipelined K3 (k_spmv_p): when no tile is a chunked heavy row or has > 85 rows
   int64_t inc_stride = 0;

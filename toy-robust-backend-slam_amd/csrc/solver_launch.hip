@@ -90,7 +90,9 @@ int pgo_handle::spmv_enqueue(const double* p, double* yout, double* dot_part, in
 #endif
     default:
 #ifdef PGO_EXPERIMENTS
-      if (spmv_pipe && spmv_one_tile && k3_tw) {
+      if (spmv_pipe && spmv_one_tile && k3_nt == 2) hipLaunchKernelGGL((dev::k_spmv_1<dev::WG, 2>), dim3(g_spmv), dim3(2 * dev::WG), 0, stream, A);
+      else if (spmv_pipe && spmv_one_tile && k3_nt == 4) hipLaunchKernelGGL((dev::k_spmv_1<dev::WG, 4>), dim3(g_spmv), dim3(4 * dev::WG), 0, stream, A);
+      else if (spmv_pipe && spmv_one_tile && k3_tw) {
         A.tile_desc = k3_desc;
         A.n_tiles = n_k3;
         if (k3_tw == 64) hipLaunchKernelGGL(dev::k_spmv_1<64>, dim3(g_spmv), dim3(64), 0, stream, A);
