@@ -195,9 +195,9 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
         int per_cu = 4;
         if (const char* ge = PGO_EXP_ENV("PGO_SPMV_PIPE_WGS")) per_cu = std::max(1, atoi(ge));
         g_spmv = ((std::min(std::max(1, S.n_tiles()), 256 * per_cu) + 7) / 8) * 8;
-        // Large graphs: one tile per workgroup (k_spmv_1) -- 154 us against the pipelined form's 164-166 us at 1M poses; test
-        // hook "spmv_pipe" = 2 keeps k_spmv_p there.  Up to 4096 tiles the persistent forms stay (fewer partials, no
-        // k_finalize launch in a latency-bound iteration).
+        // Large graphs: one tile per workgroup (k_spmv_1) -- 151 us against the pipelined form's 164-166 us at 1M poses; test
+        // hook "spmv_pipe" = 2 keeps k_spmv_p there.  Up to 4096 tiles the persistent forms stay: fewer partials, no
+        // k_fold_partials launch in a latency-bound iteration (100k poses, 3.2k tiles: 247 vs 237 GN it/s; 60k: 369 vs 329).
         int one_tile_min = 4096;
         if (const char* om = PGO_EXP_ENV("PGO_ONE_TILE_MIN")) one_tile_min = atoi(om);
         if (S.n_tiles() > one_tile_min && knob("spmv_pipe") != 2 && up8(S.n_tiles()) + 8 + 512 <= part_cap) {
