@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--k3", choices=["auto", "pipelined"], default="auto",
                     help="A/B switch: 'pipelined' keeps the persistent software-pipelined product kernel on large graphs (test hook spmv_pipe = 2)")
+    ap.add_argument("--layout", choices=["auto", "dense"], default="auto",
+                    help="A/B switch: 'dense' keeps the dense incidence layout on large graphs (test hook pad_tiles = 0)")
     ap.add_argument("--pcg-loop", choices=["auto", "one-reduction"], default="auto",
                     help="A/B switch: 'one-reduction' runs the several-rank PCG loop (Chronopoulos-Gear) on one rank too (test hook single_reduction = 1)")
     ap.add_argument("--comm", choices=["rccl", "shm"], default="rccl",
@@ -143,6 +145,8 @@ def main():
         sys.exit(3)
     if args.k3 == "pipelined":
         P.set_knob("spmv_pipe", 2)
+    if args.layout == "dense":
+        P.set_knob("pad_tiles", 0)
     if args.pcg_loop == "one-reduction":
         P.set_knob("single_reduction", 1)
     rehearsal = args.comm == "shm"

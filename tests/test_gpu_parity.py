@@ -559,6 +559,33 @@ def test_direct_solve_other_options_and_reproducibility(pgo, oracle):
     s.close()
 
 
+def test_padded_tile_slots_change_nothing(pgo):
+    """large graphs keep every row tile's incidences in 256 slots of its own (pgo::pad_tiles_to_slots: K3 then finds a tile's
+    blocks from the tile number alone); the null incidences behind the real ones add exact zeros to the same sums in the
+    same order, so assembly, product and the LM trajectory are BITWISE what the dense layout gives (test hook pad_tiles = 0)"""
+    g = pgo.synth_manhattan(160000, 4.0, 0.10, 5)
+    x = np.random.default_rng(3).standard_normal(3 * g.n_poses)
+    out = {}
+    for pad in (0, -1):
+        pgo.set_knob("pad_tiles", pad)
+        try:
+            s = pgo.Solver(g, pgo.Options(method=1, max_iters=3, pcg_rtol=0.1, pcg_max_iters=200))
+        finally:
+            pgo.set_knob("pad_tiles", -1)
+        assert s.info().n_tiles > 4096 and s.info().n_incidences == 2 * g.n_edges
+        s.lm_begin()
+        s.lm_step(3)
+        y = s.spmv(x)
+        grad, hd = s.normal_eq()
+        out[pad] = (grad, hd, y, s.poses().copy(), [(r["pcg_iters"], r["cost"]) for r in s.iter_records()], s.info().device_bytes)
+        s.close()
+    for a, b in zip(out[0][:4], out[-1][:4]):
+        np.testing.assert_array_equal(a, b)
+    assert out[0][4] == out[-1][4]
+    assert out[-1][5] > out[0][5]            # (the slots are really there: a little more device memory)
+
+
+
 def test_product_kernels_agree(pgo, oracle):
     """K3 has three product kernels -- k_spmv_1 (plain tiles, one per workgroup: large graphs), the software-pipelined
     k_spmv_p (plain tiles, persistent workgroups) and k_spmv_t (every other case) -- and small graphs take the

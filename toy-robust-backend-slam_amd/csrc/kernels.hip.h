@@ -629,8 +629,13 @@ __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
       if (tid < nq) {
         const int q = q0 + tid;
         const int ed = A.inc_edge[q], col = A.inc_col[q], roff = A.inc_rowoff[q];
-        const bool first_of_pair = tid == 0 || roff != (int)A.inc_rowoff[q - 1] || A.inc_col[q - 1] != col;
-        asm_incidence<SC, INFO>(A, q, ed, (int64_t)col, r0 + roff, first_of_pair, tid, scr);
+        if (ed >= 0) {
+          const bool first_of_pair = tid == 0 || roff != (int)A.inc_rowoff[q - 1] || A.inc_col[q - 1] != col;
+          asm_incidence<SC, INFO>(A, q, ed, (int64_t)col, r0 + roff, first_of_pair, tid, scr);
+        } else {   // a null incidence of a padded tile (pad_tiles_to_slots): contributes 0; its block stays the zero it was allocated as
+#pragma unroll
+          for (int c = 0; c < NS; ++c) scr[c][tid] = 0.0;
+        }
       }
       __syncthreads();
       for (int idx = tid; idx < nrows * NS; idx += WG) {
@@ -1019,7 +1024,10 @@ __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
 // retires.  Measured on the box where the pipelined k_spmv_p (1024 persistent workgroups) takes 164-166 us: k_spmv_t with
 // 2048 / 4096 / 8192 / 16384 / 31808 workgroups 188 / 179 / 173 / 167 / 154 us, this kernel 151 us.  Plain tiles only
 // (<= TW incidences, <= TW / 3 rows, TW threads); its dot partials -- one per tile -- are folded by k_fold_partials.
-template <int TW = WG, int NT = 1>
+// PAD: the padded-slot layout (pgo::pad_tiles_to_slots): tile t's column indices and blocks sit at TW t, every lane has a slot
+// (null incidences: zero block), so they are requested WITHOUT waiting for the tile's descriptor -- one dependent round trip
+// less per workgroup.
+template <int TW = WG, int NT = 1, bool PAD = false>
 __global__ __launch_bounds__(TW * NT) void k_spmv_1(SpmvArgs A) {
   // NT > 1 (experiment builds): NT consecutive tiles per workgroup, one per group of TW threads, NT times fewer dot partials
   __shared__ double scr[NT][3][TW];
@@ -1032,8 +1040,9 @@ __global__ __launch_bounds__(TW * NT) void k_spmv_1(SpmvArgs A) {
   const int t = xr.begin * NT + grp;
   if (xr.begin < xr.end) {       // (as many workgroups as items: at most one per workgroup)
     const int4 d = t < A.n_tiles ? A.tile_desc[t] : make_int4(0, 0, 0, 0);
-    const int r0 = d.x, nrows = d.y, q0 = d.z, nq = d.w;
-    const bool on = tid < nq, pv = tid < nrows * 3;
+    const int r0 = d.x, nrows = d.y, nq = d.w;
+    const int q0 = PAD ? TW * t : d.z;
+    const bool on = PAD ? t < A.n_tiles : tid < nq, pv = tid < nrows * 3;
     int col = 0;
     if (on) col = ld_stream(A.inc_col + q0 + tid);
     // row operands first (independent of the column index): row a of the diagonal block with D'D folded in, own direction
@@ -1042,8 +1051,8 @@ __global__ __launch_bounds__(TW * NT) void k_spmv_1(SpmvArgs A) {
     if (pv) {
       a = tid / nrows;
       row = r0 + (tid - a * nrows);
-      lo = A.inc_ptr[row] - q0;
-      hi = A.inc_ptr[row + 1] - q0;
+      lo = A.inc_ptr[row] - d.z;
+      hi = A.inc_ptr[row + 1] - d.z;
       const int i0 = (a == 0) ? 0 : a, i1 = (a == 0) ? 1 : (a == 1 ? 3 : 4), i2 = (a == 2) ? 5 : (a == 1 ? 4 : 2);
       const double* hdg = A.with_d2 ? A.hdd + ((int64_t)a * n + row) : A.hd + ((int64_t)(a == 0 ? 0 : (a == 1 ? 3 : 5)) * n + row);
       const double dg = ld_stream(hdg);

@@ -52,7 +52,9 @@ struct ShardStructure {
 
   // incidences of the owned rows (row-major):  row i -> [inc_ptr[i-lo], inc_ptr[i-lo+1])
   // each incidence = (local edge, side) ; side 0: row is Edge::a, 1: row is Edge::b
-  int64_t n_inc = 0;
+  int64_t n_inc = 0;                    // length of the incidence arrays (with padded tiles: the slots, null incidences included)
+  int64_t n_inc_real = 0;               // incidences proper (= 2 x edges between owned rows + 1 x cut edges)
+  bool padded = false;                  // pad_tiles_to_slots(): tile t owns the slots [TILE_INC t, TILE_INC (t + 1))
   std::vector<int32_t> inc_ptr;         // n_loc + 1
   std::vector<int32_t> inc_edge;        // (local edge << 1) | side
   std::vector<int32_t> inc_col;         // global pose position of the other endpoint
@@ -86,6 +88,7 @@ int build_shard_structure(int32_t n_poses, int32_t n_edges, const int32_t* ia, c
 
 // processing order of the row tiles for K3 (structure.cpp): order[k] = tile that takes the k-th turn
 void compute_tile_order(const ShardStructure& S, std::vector<int32_t>* order);
+bool pad_tiles_to_slots(ShardStructure* S);
 
 // locality ordering (structure.cpp): perm[i] = new position of pose i
 int compute_pose_order(int32_t n_poses, int32_t n_edges, const int32_t* ia, const int32_t* ib, int32_t segment,

@@ -8,7 +8,7 @@ struct Knob {
   const char* name;
   std::atomic<long long> value;
 };
-Knob g_knobs[] = {{"spmv_pipe", {-1}}, {"fused_p", {-1}}, {"direct_fail_at", {-1}}, {"direct_setup_fail", {-1}}, {"single_reduction", {-1}}, {"verify_residual", {-1}}, {"shm_timeout_s", {-1}}};
+Knob g_knobs[] = {{"spmv_pipe", {-1}}, {"fused_p", {-1}}, {"direct_fail_at", {-1}}, {"direct_setup_fail", {-1}}, {"single_reduction", {-1}}, {"verify_residual", {-1}}, {"shm_timeout_s", {-1}}, {"pad_tiles", {-1}}};
 }  // namespace
 long long knob(const char* name) {
   for (Knob& k : g_knobs)
@@ -348,7 +348,7 @@ int pgo_get_info(const pgo_t* h, pgo_handle_info* out) {
   out->row_hi = h->S.hi;
   out->n_edges_local = h->S.n_edges_local;
   out->n_tiles = h->S.n_tiles();
-  out->n_incidences = h->S.n_inc;
+  out->n_incidences = h->S.n_inc_real;
   out->pcg_block_poses = h->grp_B;
   out->pcg_chain_len = h->chain_len;
   out->chain_kernel = h->chain_chunk;
@@ -527,7 +527,7 @@ int pgo_bench_assemble(pgo_t* h, int reps, pgo_kernel_stats* out) {
   // every record read once (112 B/edge); per incidence 8 B indices + 72 B block written; per row 72 B out + 4 B
   // pointer + 24 B scale
   // chain preconditioner: + the 72-byte block (i, i-1) per row into the factorisation's input record
-  out->algorithmic_bytes = 112.0 * h->S.n_edges_local + 80.0 * (double)h->S.n_inc + (100.0 + (h->chain_len ? 72.0 : 0.0)) * h->S.n_loc;
+  out->algorithmic_bytes = 112.0 * h->S.n_edges_local + 80.0 * (double)h->S.n_inc_real + (100.0 + (h->chain_len ? 72.0 : 0.0)) * h->S.n_loc;
   return PGO_OK;
 }
 
@@ -564,10 +564,10 @@ int pgo_bench_spmv(pgo_t* h, int reps, pgo_kernel_stats* out) {
   h->spmv_ablate = 0;
   PGOC(st_ab);
   out->ms_avg = ms;
-  out->units = h->S.n_inc + h->S.n_loc;
+  out->units = h->S.n_inc_real + h->S.n_loc;
   // 76 B per off-diagonal block (value + column) ; per row: 48 B diagonal planes + 24 B D'D + 4 B row
   // pointer + 24 B y + 24 B p; the product kernel k_spmv_p reads the diagonal with D'D folded in (k_prepare): 24 B less
-  out->algorithmic_bytes = 76.0 * (double)h->S.n_inc + (h->spmv_pipe ? 100.0 : 124.0) * h->S.n_loc;
+  out->algorithmic_bytes = 76.0 * (double)h->S.n_inc_real + (h->spmv_pipe ? 100.0 : 124.0) * h->S.n_loc;
   return PGO_OK;
 }
 

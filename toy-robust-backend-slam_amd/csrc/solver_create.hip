@@ -88,6 +88,11 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   }
   PGOC(pgo::build_shard_structure(N, E, ia, ib, meas, kind, opt.method, world, rank, chain_len ? chain_len : grp_B, &S,
                                   tile_breaks_h.empty() ? nullptr : &tile_breaks_h));
+  // Graphs large enough for the one-tile-per-workgroup product kernel (k_spmv_1, below) get the padded-slot layout: every
+  // tile's incidences at TILE_INC t (structure.cpp, pad_tiles_to_slots).  Test hook "pad_tiles" = 0 keeps the dense layout.
+  int one_tile_min = 4096;
+  if (const char* om = PGO_EXP_ENV("PGO_ONE_TILE_MIN")) one_tile_min = atoi(om);
+  if (!batch_mode && S.n_tiles() > one_tile_min && knob("pad_tiles") != 0) (void)pgo::pad_tiles_to_slots(&S);
   n_full = (int64_t)world * S.rows_per_rank;
   const int64_t EL = S.n_edges_local, NL = S.n_loc;
   inc_stride = ((S.n_inc + 63) / 64) * 64;  // whole 64-incidence groups (dev::hoff_index)
@@ -198,8 +203,6 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
         // Large graphs: one tile per workgroup (k_spmv_1) -- 151 us against the pipelined form's 164-166 us at 1M poses; test
         // hook "spmv_pipe" = 2 keeps k_spmv_p there.  Up to 4096 tiles the persistent forms stay: fewer partials, no
         // k_fold_partials launch in a latency-bound iteration (100k poses, 3.2k tiles: 247 vs 237 GN it/s; 60k: 369 vs 329).
-        int one_tile_min = 4096;
-        if (const char* om = PGO_EXP_ENV("PGO_ONE_TILE_MIN")) one_tile_min = atoi(om);
         if (S.n_tiles() > one_tile_min && knob("spmv_pipe") != 2 && up8(S.n_tiles()) + 8 + 512 <= part_cap) {
           spmv_one_tile = true;
           g_spmv = up8(S.n_tiles());
@@ -210,7 +213,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
             if (k3_nt) g_spmv = up8((S.n_tiles() + k3_nt - 1) / k3_nt);
           }
           // PGO_K3_TW = 64 | 128: k_spmv_1 on its own, finer tiles (<= TW incidences, TW threads per workgroup)
-          if (const char* tw = getenv("PGO_K3_TW")) {
+          if (const char* tw = S.padded ? nullptr : getenv("PGO_K3_TW")) {   // (on the dense layout only: run with the hook pad_tiles = 0)
             const int TW = atoi(tw);
             std::vector<int4> d3;
             bool fits = TW == 64 || TW == 128;

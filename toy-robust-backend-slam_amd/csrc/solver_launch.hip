@@ -99,7 +99,8 @@ int pgo_handle::spmv_enqueue(const double* p, double* yout, double* dot_part, in
         else hipLaunchKernelGGL(dev::k_spmv_1<128>, dim3(g_spmv), dim3(128), 0, stream, A);
       } else
 #endif
-      if (spmv_pipe && spmv_one_tile) hipLaunchKernelGGL(dev::k_spmv_1<>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+      if (spmv_pipe && spmv_one_tile && S.padded) hipLaunchKernelGGL((dev::k_spmv_1<dev::WG, 1, true>), dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+      else if (spmv_pipe && spmv_one_tile) hipLaunchKernelGGL(dev::k_spmv_1<>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
       else if (spmv_pipe) hipLaunchKernelGGL(dev::k_spmv_p<dev::PS>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
       else hipLaunchKernelGGL(dev::k_spmv_t<0>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
   }
