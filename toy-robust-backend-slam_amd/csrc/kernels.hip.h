@@ -613,6 +613,8 @@ __device__ __forceinline__ void asm_store_row(const AsmArgs& A, int c, int row, 
 // triples of the next tile prefetched, double-buffered staging, ~1000-1500 workgroups) was built and measured SLOWER:
 // 505 us against 409 us at 1M poses -- with 39 KB of LDS only four workgroups fit a compute unit, and the records
 // themselves (the long pole) were still requested only after the previous tile's barrier.
+// (On the padded-slot layout, pgo::pad_tiles_to_slots, a variant that requests the tile's index triples at WG t without
+// waiting for the descriptor was measured SLOWER: 424-430 against 413-415 us.)
 template <bool SC, bool INFO>
 __global__ __launch_bounds__(WG) void k_assemble(AsmArgs A) {
   static_assert(!(SC && INFO), "switchable constraints have no information-weighted form here");
