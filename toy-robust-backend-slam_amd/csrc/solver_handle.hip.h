@@ -283,13 +283,36 @@ struct pgo_handle {
   int spmv_nt = 1;      // non-temporal H-stream loads in k_spmv (PGO_SPMV_NT=0 turns them off): 179 -> 166 us at 1M poses
   bool multi_rank() const { return comm && (comm->world > 1 || force_collectives); }
 
+#ifdef PGO_EXPERIMENTS
+  char* arena = nullptr;     // PGO_ARENA_MB: one hipMalloc for the whole handle, buffers carved out at 2-MiB boundaries
+  size_t arena_bytes = 0, arena_off = 0;
+#endif
   template <class T>
   int dalloc(T** out, int64_t n) {
     void* p = nullptr;
     size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return fail(PGO_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    allocs.push_back(p);
+    hipError_t e = hipSuccess;
+#ifdef PGO_EXPERIMENTS
+    if (!arena && !arena_bytes) {
+      const char* am = getenv("PGO_ARENA_MB");
+      arena_bytes = am ? (size_t)atoll(am) << 20 : 1;
+      if (am && hipMalloc((void**)&arena, arena_bytes) == hipSuccess) allocs.push_back(arena);
+      else arena = nullptr;
+    }
+    // PGO_ARENA_ALIGN (bytes, default 2 MiB): carving granularity; PGO_ARENA_SKEW (bytes): extra gap in front of buffer k = k x skew
+    static const size_t a_align = getenv("PGO_ARENA_ALIGN") ? std::max<size_t>(256, (size_t)atoll(getenv("PGO_ARENA_ALIGN"))) : ((size_t)2 << 20);
+    static const size_t a_skew = getenv("PGO_ARENA_SKEW") ? (size_t)atoll(getenv("PGO_ARENA_SKEW")) : 0;
+    const size_t start = ((arena_off + a_align - 1) / a_align) * a_align + a_skew * (allocs.size() % 61);
+    if (arena && start + bytes <= arena_bytes) {
+      p = arena + start;
+      arena_off = start + bytes;
+    } else
+#endif
+    {
+      e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) return fail(PGO_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+      allocs.push_back(p);
+    }
     device_bytes += (int64_t)bytes;
     e = hipMemsetAsync(p, 0, bytes, stream);
     if (e != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
