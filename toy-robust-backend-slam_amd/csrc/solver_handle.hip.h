@@ -309,7 +309,17 @@ struct pgo_handle {
     } else
 #endif
     {
-      e = hipMalloc(&p, bytes);
+      size_t ask = bytes;
+#ifdef PGO_EXPERIMENTS
+      // PGO_ALLOC_POW2=1: sizes rounded up to a power of two (one buddy block per buffer); =2: plus 2 MiB (never one block)
+      static const int pow2 = getenv("PGO_ALLOC_POW2") ? atoi(getenv("PGO_ALLOC_POW2")) : 0;
+      if (pow2 && bytes >= ((size_t)1 << 20)) {
+        size_t r = (size_t)1 << 20;
+        while (r < bytes) r <<= 1;
+        ask = pow2 == 2 ? r + ((size_t)2 << 20) : r;
+      }
+#endif
+      e = hipMalloc(&p, ask);
       if (e != hipSuccess) return fail(PGO_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
       allocs.push_back(p);
     }
