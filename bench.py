@@ -336,7 +336,8 @@ def main():
             "halo_exchange_check": halo_check,
             "handle": {k: v for k, v in s.info().as_dict().items() if k in ("pcg_block_poses", "pcg_chain_len", "chain_kernel", "n_tiles", "pose_ordering",
                                                                            "n_incidences", "halo_send_rows", "halo_recv_rows", "device_bytes",
-                                                                           "host_enqueue_us_per_pcg_iter", "pcg_graph_replay")},
+                                                                           "host_enqueue_us_per_pcg_iter", "pcg_graph_replay", "pcg_single_reduction", "pcg_coarse_poses",
+                                                                           "linear_solver")},
         }
         # HBM bytes per launch of k_spmv from the committed rocprofv3 --pmc passes -- only if they were taken on THESE
         # kernel sources (the file records a digest of them); otherwise null rather than a stale figure
