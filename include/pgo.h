@@ -409,7 +409,8 @@ int pgo_debug_normal_eq(pgo_t* h, double* g_or_null, double* hdiag_or_null);    
  *                        more product per solve) instead of the recurrence residual the loop stopped on
  *   "shm_timeout_s"      seconds a rank of the shm TEST communicator waits at a barrier before it gives up (default 120)
  *   "pad_tiles"          0 = large graphs keep the dense incidence layout (default: every row tile padded to 256 incidence
- *                        slots of its own, so that K3 finds a tile's blocks from its number alone; same results)
+ *                        slots of its own, so that K3 finds a tile's blocks from its number alone; same results);
+ *                        1 = that layout and its product kernel (k_spmv_1) on a graph of any size
  * Unknown name: PGO_ERR_INVALID_ARG.                                                                              */
 int pgo_debug_set_knob(const char* name, long long value);                        /* [host] */
 /* sharding plan of a graph over `world` ranks: for rank r, rows [lo, hi) and the

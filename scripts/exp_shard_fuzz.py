@@ -15,7 +15,10 @@ for case in range(n_cases):
     world = int(rng.choice([2, 3, 4]))
     opts = dict(method=int(rng.choice([0, 1, 2])), fixed_pose=int(rng.choice([0, -1])), max_iters=3, pcg_rtol=float(rng.choice([1e-12, 1e-3])), pcg_max_iters=100000,
                 linear_solver=1, halo_exchange=int(rng.choice([0, 1])), pcg_chain_len=int(rng.choice([-1, 8, 64, 0])))
-    cfg = dict(graph="recipe", recipe=recipe, options=opts, knobs=dict(shm_timeout_s=15))
+    knobs = dict(shm_timeout_s=15)
+    if rng.integers(2):
+        knobs["pad_tiles"] = 1        # the large-graph layout (padded tile slots, k_spmv_1, folded partials) on small shards
+    cfg = dict(graph="recipe", recipe=recipe, options=opts, knobs=knobs)
     tag = "c%d" % case
     try:
         ref, rp = run(1, cfg, tmp, tag=tag + "r")
@@ -27,8 +30,8 @@ for case in range(n_cases):
         dp = float(np.abs(pp[0] - rp[0]).max())
         tight = opts["pcg_rtol"] < 1e-6
         good = ok and hist and (not tight or (dc < 1e-8 and dp < 1e-6 * max(1.0, np.abs(rp[0]).max())))
-        print("case %2d n=%4d world=%d %s: ranks identical %s, history %s, d cost %.1e, d poses %.1e, pcg %d vs %d %s" % (
-            case, n, world, json.dumps(opts), ok, hist, dc, dp, res[0]["summary"]["total_pcg_iters"], ref[0]["summary"]["total_pcg_iters"], "" if good else "  <-- CHECK"), flush=True)
+        print("case %2d n=%4d world=%d %s pad %s: ranks identical %s, history %s, d cost %.1e, d poses %.1e, pcg %d vs %d %s" % (
+            case, n, world, json.dumps(opts), knobs.get("pad_tiles", -1), ok, hist, dc, dp, res[0]["summary"]["total_pcg_iters"], ref[0]["summary"]["total_pcg_iters"], "" if good else "  <-- CHECK"), flush=True)
         bad += not good
     except AssertionError as e:
         print("case %2d n=%4d world=%d recipe %r %s: FAILED\n%s" % (case, n, world, recipe, json.dumps(opts), str(e)[-1500:]), flush=True)

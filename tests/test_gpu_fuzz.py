@@ -67,14 +67,33 @@ def pose_graphs(draw):
     return make_graph(n, seed, p_chain, n_extra, hub, dup) + (fixed, method)
 
 
+class _layout:
+    """0: the library's choice; 1: the large-graph layout (every row tile in 256 incidence slots of its own, null incidences behind
+    the real ones) with its product kernel k_spmv_1 and the folded dot partials, forced on a small graph through the test hooks;
+    2: that layout under the small-graph PCG loop (direction update inside the product, k_spmv_t MODE 5)"""
+    def __init__(self, pgo, mode):
+        self.pgo, self.mode = pgo, mode
+
+    def __enter__(self):
+        if self.mode:
+            self.pgo.set_knob("pad_tiles", 1)
+        if self.mode == 1:
+            self.pgo.set_knob("fused_p", 0)
+
+    def __exit__(self, *exc):
+        self.pgo.set_knob("pad_tiles", -1)
+        self.pgo.set_knob("fused_p", -1)
+
+
 @settings(**SETTINGS)
-@given(pose_graphs())
-def test_kernels_and_one_lm_iteration_against_the_oracle(pgo, oracle, case):
+@given(pose_graphs(), st.sampled_from([0, 1, 1, 2]))
+def test_kernels_and_one_lm_iteration_against_the_oracle(pgo, oracle, case, layout):
     poses, ia, ib, meas, kind, fixed, method = case
     g = pgo.Graph.from_arrays(poses, ia, ib, meas, kind)
     og = oracle_graph(oracle, g)
     m12 = method if method != 2 else 1        # (the oracle's METHOD 2 evaluator has its own entry point: kernels are compared on 0 / 1)
-    s = pgo.Solver(g, pgo.Options(method=m12, fixed_pose=fixed, linear_solver=1))
+    with _layout(pgo, layout):
+        s = pgo.Solver(g, pgo.Options(method=m12, fixed_pose=fixed, linear_solver=1))
     # K1
     c, r, J = s.evaluate()
     oc, orr, oJ = oracle.evaluate(og, method=m12)
@@ -92,7 +111,8 @@ def test_kernels_and_one_lm_iteration_against_the_oracle(pgo, oracle, case):
     # two LM iterations, tight PCG, against the C port of the same policy (METHOD 0 / 1)
     if method != 2 and g.n_edges:
         kw = dict(method=method, fixed_pose=fixed, max_iters=2, pcg_rtol=1e-12, pcg_max_iters=100000)
-        s2 = pgo.Solver(g, pgo.Options(linear_solver=1, **kw))
+        with _layout(pgo, layout):
+            s2 = pgo.Solver(g, pgo.Options(linear_solver=1, **kw))
         summ = s2.solve()
         ores = oracle.lm_pcg(og, oracle.Options(**kw))
         assert [a["step_ok"] for a in s2.iter_records()] == [b["step_ok"] for b in ores.records]

@@ -92,6 +92,7 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   // tile's incidences at TILE_INC t (structure.cpp, pad_tiles_to_slots).  Test hook "pad_tiles" = 0 keeps the dense layout.
   int one_tile_min = 4096;
   if (const char* om = PGO_EXP_ENV("PGO_ONE_TILE_MIN")) one_tile_min = atoi(om);
+  if (knob("pad_tiles") == 1) one_tile_min = 0;   // (test hook: the large-graph layout and product kernel on a graph of any size)
   if (!batch_mode && S.n_tiles() > one_tile_min && knob("pad_tiles") != 0) (void)pgo::pad_tiles_to_slots(&S);
   n_full = (int64_t)world * S.rows_per_rank;
   const int64_t EL = S.n_edges_local, NL = S.n_loc;
