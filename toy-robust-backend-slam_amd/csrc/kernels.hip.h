@@ -1704,9 +1704,13 @@ __global__ void k_chain_dupfix(const int32_t* __restrict__ rows, int n_rows, con
 }
 
 // One thread per segment, sequential along the chain (seg_len dependent 3x3 steps; once per LM iteration); each step
-// reads one 128-byte record.
-//  * The records do not depend on the recurrence: the loads of the next PF steps are kept in flight while a step computes
-//    (a ring of PF records in registers), so the chain is paced by the 3x3 arithmetic, not by a memory round trip per step.
+// reads one 128-byte record.  One wavefront = 64 segments.
+//  * The records reach the threads THROUGH LDS: a thread's own records are 128 bytes in a line of their own, so loading
+//    them per thread makes every wave instruction touch 64 lines (8 KB of distinct lines per step in flight; the first
+//    form of this kernel kept a ring of four such steps per thread and was paced by the L1).  Instead the wavefront
+//    loads, for each of its 64 segments, the 1 KB that holds the segment's next eight records with ONE coalesced
+//    LDS-DMA instruction (64 lanes x 16 bytes, global_load_lds) into the other half of a double-buffered LDS tile while
+//    the current eight steps compute (segment stride 65 x 16 bytes: conflict-free 16-byte reads).
 //  * The factor planes are transposed for the APPLY kernels (step k of all 64 lanes = one 512-byte access), which makes
 //    this thread's own 15 values per step land 8 bytes apiece in 15 different lines -- 468 MB written for 120 MB of
 //    factors at 1M poses.  So the results of GS = 8 consecutive steps are kept in registers and flushed together: in the
@@ -1715,36 +1719,42 @@ __global__ void k_chain_dupfix(const int32_t* __restrict__ rows, int n_rows, con
 template <int CHUNK>
 __global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ rec, int n_loc, int n_pad, int seg_len,
                                                      double* __restrict__ cw, double* __restrict__ cs) {
-  constexpr int PF = 4, GS = 8, RUN = GS / CHUNK;   // RUN adjacent doubles per (plane, k) and group
-  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int GS = 8, RUN = GS / CHUNK;   // RUN adjacent doubles per (plane, k) and group
+  constexpr int SEGS = 64, STR = GS * 8 + 1;   // double2 per segment and buffer (+ 1: bank spread)
+  __shared__ double2 stage[2][SEGS * STR];
+  const int lane = threadIdx.x;
   const int64_t n = n_loc, np = n_pad;
-  const int64_t s0 = (int64_t)seg * seg_len;
-  if (s0 >= n) return;
-  const int64_t s1 = s0 + seg_len < n ? s0 + seg_len : n;
-  double2 ring[PF][8];
-#pragma unroll
-  for (int k = 0; k < PF; ++k) {
-    const int64_t i = s0 + k < s1 ? s0 + k : s1 - 1;
-    const double2* in = reinterpret_cast<const double2*>(rec + i * CHAIN_REC);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) ring[k][c] = in[c];
-  }
+  const int64_t seg0 = (int64_t)blockIdx.x * SEGS;
+  const int64_t s0 = (seg0 + lane) * seg_len;
+  const bool live = s0 < n;
+  const int64_t s1 = !live ? s0 : (s0 + seg_len < n ? s0 + seg_len : n);
+  const int n_groups = (seg_len + GS - 1) / GS;
+  // the records of group g of every segment of this wavefront, straight into LDS (LDS-DMA: no register destination, the
+  // wave instruction's 64 x 16 bytes land lane-linear at the segment's 1-KB slot): lane j takes 16 bytes of segment sg's
+  // eight records
+  auto fetch = [&](int g, int buf) {
+#pragma unroll 8
+    for (int sg = 0; sg < SEGS; ++sg) {
+      int64_t row = (seg0 + sg) * seg_len + (int64_t)g * GS + (lane >> 3);
+      row = row < n ? row : n - 1;    // (never used: steps beyond the segment or the shard are skipped below)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + row * CHAIN_REC + 2 * (lane & 7)),
+                                       (__attribute__((address_space(3))) void*)(&stage[buf][sg * STR]), 16, 0, 0);
+    }
+  };
+  fetch(0, 0);
+  __syncthreads();   // (drains the DMA: vmcnt(0) in front of the barrier)
   double p00 = 0.0, p01 = 0.0, p02 = 0.0, p11 = 0.0, p12 = 0.0, p22 = 0.0;  // S_{i-1}^-1
-  for (int64_t ib = s0; ib < s1; ib += GS) {
+  for (int g = 0; g < n_groups; ++g) {
+    const int buf = g & 1;
+    if (g + 1 < n_groups) fetch(g + 1, buf ^ 1);   // (buffer buf ^ 1 was last read in group g - 1, a barrier ago)
+    const int64_t ib = s0 + (int64_t)g * GS;
     double OUT[GS][15];   // W (9) | S^-1 (6) of the group's steps
 #pragma unroll
     for (int k = 0; k < GS; ++k) {
       const int64_t i = ib + k;
-      if (i < s1) {
-        const int slot = k % PF;
-        const double2 v0 = ring[slot][0], v1 = ring[slot][1], v2 = ring[slot][2], v3 = ring[slot][3], v4 = ring[slot][4],
-                      v5 = ring[slot][5], v6 = ring[slot][6], v7 = ring[slot][7];
-        {  // refill this slot with the record PF steps ahead
-          const int64_t j = i + PF < s1 ? i + PF : s1 - 1;
-          const double2* in = reinterpret_cast<const double2*>(rec + j * CHAIN_REC);
-#pragma unroll
-          for (int c = 0; c < 8; ++c) ring[slot][c] = in[c];
-        }
+      if (live && i < s1) {
+        const double2* in = &stage[buf][lane * STR + k * 8];
+        const double2 v0 = in[0], v1 = in[1], v2 = in[2], v3 = in[3], v4 = in[4], v5 = in[5], v6 = in[6], v7 = in[7];
         double a00 = v0.x, a01 = v0.y, a02 = v1.x, a11 = v1.y, a12 = v2.x, a22 = v2.y;
         double W[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (i > s0) {
@@ -1776,8 +1786,12 @@ __global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ 
         OUT[k][9] = p00; OUT[k][10] = p01; OUT[k][11] = p02; OUT[k][12] = p11; OUT[k][13] = p12; OUT[k][14] = p22;
       }
     }
+    // the next group's records have landed (and every lane is done with this buffer).  BEFORE this group's stores are
+    // issued: the barrier's wait covers every outstanding memory operation, and the stores of the previous group have had a
+    // whole group's arithmetic to complete, these would not have
+    __syncthreads();
     // ---- flush the group
-    if (ib + GS <= s1 && (ib % GS) == 0) {
+    if (live && ib + GS <= s1 && (ib % GS) == 0) {
       // whole aligned group: pose ib + kk + CHUNK m (m < RUN) sits at chain_tidx_g(ib + kk) + m -- RUN adjacent doubles
 #pragma unroll
       for (int kk = 0; kk < CHUNK; ++kk) {
@@ -1790,7 +1804,7 @@ __global__ __launch_bounds__(64) void k_chain_factor(const double* __restrict__ 
             *reinterpret_cast<double2*>(dst + m) = make_double2(OUT[kk + CHUNK * m][c], OUT[kk + CHUNK * (m + 1)][c]);
         }
       }
-    } else {
+    } else if (live) {
 #pragma unroll
       for (int k = 0; k < GS; ++k) {
         const int64_t i = ib + k;
