@@ -3,7 +3,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 O=gpurun_out/factor; mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 scripts/k3_probe.py -1 > $O/trace.log 2>&1 || { tail -5 $O/trace.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 scripts/k3_probe.py -1 1000000 > $O/trace.log 2>&1 || { tail -5 $O/trace.log; exit 1; }
 python3 - <<PY
 import csv, glob
 for f in glob.glob("$O/trace/**/*kernel_stats.csv", recursive=True):
