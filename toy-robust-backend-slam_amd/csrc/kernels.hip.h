@@ -1026,25 +1026,26 @@ __global__ __launch_bounds__(WG) void k_spmv_p(SpmvArgs A) {
 // retires.  Measured on the box where the pipelined k_spmv_p (1024 persistent workgroups) takes 164-166 us: k_spmv_t with
 // 2048 / 4096 / 8192 / 16384 / 31808 workgroups 188 / 179 / 173 / 167 / 154 us, this kernel 151 us.  Plain tiles only
 // (<= TW incidences, <= TW / 3 rows, TW threads); its dot partials -- one per tile -- are folded by k_fold_partials.
-// PAD: the padded-slot layout (pgo::pad_tiles_to_slots): tile t's column indices and blocks sit at TW t, every lane has a slot
+// PAD: the padded-slot layout (pgo::pad_tiles_to_slots): tile t's column indices and blocks sit at WG t, every lane has a slot
 // (null incidences: zero block), so they are requested WITHOUT waiting for the tile's descriptor -- one dependent round trip
 // less per workgroup.
-template <int TW = WG, int NT = 1, bool PAD = false>
-__global__ __launch_bounds__(TW * NT) void k_spmv_1(SpmvArgs A) {
-  // NT > 1 (experiment builds): NT consecutive tiles per workgroup, one per group of TW threads, NT times fewer dot partials
-  __shared__ double scr[NT][3][TW];
-  __shared__ double red[16];
-  const int tid = threadIdx.x % TW, grp = threadIdx.x / TW;
+// (Measured and not kept: finer tiles of K3's own, 128 / 64 incidences and threads per workgroup -- 140-142 / 159-166 us against
+// 144-145; 2 / 4 tiles per workgroup of 512 / 1024 threads, 2 / 4 times fewer partials -- 41.3-41.5 / 39.7-40.1 against 42.0 GN it/s.)
+template <bool PAD = false>
+__global__ __launch_bounds__(WG) void k_spmv_1(SpmvArgs A) {
+  __shared__ double scr[3][WG];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
   if (A.done && *A.done) return;
   const int64_t n = A.n_loc;
-  const XcdRange xr = xcd_range((A.n_tiles + NT - 1) / NT);
+  const XcdRange xr = xcd_range(A.n_tiles);
   double dot = 0.0;
-  const int t = xr.begin * NT + grp;
-  if (xr.begin < xr.end) {       // (as many workgroups as items: at most one per workgroup)
-    const int4 d = t < A.n_tiles ? A.tile_desc[t] : make_int4(0, 0, 0, 0);
+  const int t = xr.begin;
+  if (xr.begin < xr.end) {       // (as many workgroups as tiles: at most one per workgroup)
+    const int4 d = A.tile_desc[t];
     const int r0 = d.x, nrows = d.y, nq = d.w;
-    const int q0 = PAD ? TW * t : d.z;
-    const bool on = PAD ? t < A.n_tiles : tid < nq, pv = tid < nrows * 3;
+    const int q0 = PAD ? WG * t : d.z;
+    const bool on = PAD ? true : tid < nq, pv = tid < nrows * 3;
     int col = 0;
     if (on) col = ld_stream(A.inc_col + q0 + tid);
     // row operands first (independent of the column index): row a of the diagonal block with D'D folded in, own direction
@@ -1071,14 +1072,14 @@ __global__ __launch_bounds__(TW * NT) void k_spmv_1(SpmvArgs A) {
       if (A.nt) hoff_load_nt(A.hoff, q0 + tid, h);
       else hoff_load(A.hoff, q0 + tid, h);
       gather3(A.p, (int64_t)col, p0, p1, p2);
-      scr[grp][0][tid] = h[0] * p0 + h[1] * p1 + h[2] * p2;
-      scr[grp][1][tid] = h[3] * p0 + h[4] * p1 + h[5] * p2;
-      scr[grp][2][tid] = h[6] * p0 + h[7] * p1 + h[8] * p2;
+      scr[0][tid] = h[0] * p0 + h[1] * p1 + h[2] * p2;
+      scr[1][tid] = h[3] * p0 + h[4] * p1 + h[5] * p2;
+      scr[2][tid] = h[6] * p0 + h[7] * p1 + h[8] * p2;
     }
     __syncthreads();
     if (pv) {
       double s = 0.0;
-      for (int j = lo; j < hi; ++j) s += scr[grp][a][j];
+      for (int j = lo; j < hi; ++j) s += scr[a][j];
       const double pa = (a == 0) ? pr0 : (a == 1 ? pr1 : pr2);
       s += h0 * pr0 + h1 * pr1 + h2 * pr2;
       st_stream(A.y + (3 * (int64_t)row + a), s);
@@ -1086,16 +1087,9 @@ __global__ __launch_bounds__(TW * NT) void k_spmv_1(SpmvArgs A) {
     }
   }
   dot = wave_sum(dot);
-  if (TW * NT > 64) {
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      dot = red[0];
-#pragma unroll
-      for (int w = 1; w < TW * NT / 64; ++w) dot += red[w];
-    }
-  }
-  if (threadIdx.x == 0) A.dot_part[blockIdx.x] = dot;
+  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  __syncthreads();
+  if (tid == 0) A.dot_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 // The blocks whose column lives on another rank (a few % of a shard's incidences, listed per row at create): after the

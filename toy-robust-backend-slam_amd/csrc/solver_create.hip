@@ -149,9 +149,6 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
   g_spmv = up8(std::min(std::max(1, S.n_tiles()), 2048));
   g_asm = up8(std::min(std::max(1, S.n_tiles()), 1 << 20));
   part_cap = std::max(std::max(g_edge, 2048), up8(std::max(1, S.n_tiles()))) + 8 + 512;   // (k_spmv_1: one dot partial per tile)   // (+ the coarse level's dot partials behind the one-level r.z partials)
-#ifdef PGO_EXPERIMENTS
-  if (getenv("PGO_K3_TW")) part_cap = std::max(part_cap, up8((int)(S.n_inc / 16 + NL / 16 + 16)) + 8 + 512);
-#endif
   for (int k = 0; k < N_PART; ++k) PGOC(dalloc(&part[k], part_cap));
   PGOC(dalloc(&fold_buf, 6 * 16));
 
@@ -207,35 +204,6 @@ int pgo_handle::create(int32_t N, const double* poses_h, int32_t E, const int32_
         if (S.n_tiles() > one_tile_min && knob("spmv_pipe") != 2 && up8(S.n_tiles()) + 8 + 512 <= part_cap) {
           spmv_one_tile = true;
           g_spmv = up8(S.n_tiles());
-#ifdef PGO_EXPERIMENTS
-          // PGO_K3_NT = 2 | 4: that many tiles (and 256-thread groups) per workgroup, that many times fewer dot partials
-          if (const char* nt = getenv("PGO_K3_NT")) {
-            k3_nt = atoi(nt) == 4 ? 4 : (atoi(nt) == 2 ? 2 : 0);
-            if (k3_nt) g_spmv = up8((S.n_tiles() + k3_nt - 1) / k3_nt);
-          }
-          // PGO_K3_TW = 64 | 128: k_spmv_1 on its own, finer tiles (<= TW incidences, TW threads per workgroup)
-          if (const char* tw = S.padded ? nullptr : getenv("PGO_K3_TW")) {   // (on the dense layout only: run with the hook pad_tiles = 0)
-            const int TW = atoi(tw);
-            std::vector<int4> d3;
-            bool fits = TW == 64 || TW == 128;
-            for (int32_t row = 0; fits && row < NL;) {
-              const int32_t begin = row, inc0 = S.inc_ptr[row];
-              ++row;
-              while (row < NL && S.inc_ptr[row + 1] - inc0 <= TW && (row + 1 - begin) * 3 <= TW) ++row;
-              fits = S.inc_ptr[row] - inc0 <= TW;
-              d3.push_back(make_int4(begin, row - begin, inc0, S.inc_ptr[row] - inc0));
-            }
-            if (fits && up8((int)d3.size()) + 8 + 512 <= part_cap) {
-              k3_tw = TW;
-              n_k3 = (int)d3.size();
-              g_spmv = up8(n_k3);
-              PGOC(dalloc(&k3_desc, (int64_t)d3.size()));
-              PGOC(upload(k3_desc, d3));
-              PGOC(sync());
-              fprintf(stderr, "[pgo] k_spmv_1<%d>: %d tiles\n", TW, n_k3);
-            }
-          }
-#endif
         }
       }
     }

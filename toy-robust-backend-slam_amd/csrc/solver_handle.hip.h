@@ -120,8 +120,6 @@ struct pgo_handle {
   int32_t *inc_ptr = nullptr, *inc_edge = nullptr, *inc_col = nullptr, *tile_row = nullptr;
   uint8_t* inc_rowoff = nullptr;
   int4* tile_desc = nullptr;
-  int4* k3_desc = nullptr;      // (experiment builds: k_spmv_1's own, finer tile list)
-  int k3_tw = 0, n_k3 = 0, k3_nt = 0;
   bool spmv_one_tile = false;   // the plain-tile product kernel as k_spmv_1: one tile per workgroup, as many workgroups as tiles
   bool spmv_pipe = false;   // software-pipelined K3 (k_spmv_p): when no tile is a chunked heavy row or has > 85 rows
   int64_t inc_stride = 0;
@@ -283,46 +281,15 @@ struct pgo_handle {
   int spmv_nt = 1;      // non-temporal H-stream loads in k_spmv (PGO_SPMV_NT=0 turns them off): 179 -> 166 us at 1M poses
   bool multi_rank() const { return comm && (comm->world > 1 || force_collectives); }
 
-#ifdef PGO_EXPERIMENTS
-  char* arena = nullptr;     // PGO_ARENA_MB: one hipMalloc for the whole handle, buffers carved out at 2-MiB boundaries
-  size_t arena_bytes = 0, arena_off = 0;
-#endif
   template <class T>
   int dalloc(T** out, int64_t n) {
     void* p = nullptr;
     size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);
-    hipError_t e = hipSuccess;
-#ifdef PGO_EXPERIMENTS
-    if (!arena && !arena_bytes) {
-      const char* am = getenv("PGO_ARENA_MB");
-      arena_bytes = am ? (size_t)atoll(am) << 20 : 1;
-      if (am && hipMalloc((void**)&arena, arena_bytes) == hipSuccess) allocs.push_back(arena);
-      else arena = nullptr;
-    }
-    // PGO_ARENA_ALIGN (bytes, default 2 MiB): carving granularity; PGO_ARENA_SKEW (bytes): extra gap in front of buffer k = k x skew
-    static const size_t a_align = getenv("PGO_ARENA_ALIGN") ? std::max<size_t>(256, (size_t)atoll(getenv("PGO_ARENA_ALIGN"))) : ((size_t)2 << 20);
-    static const size_t a_skew = getenv("PGO_ARENA_SKEW") ? (size_t)atoll(getenv("PGO_ARENA_SKEW")) : 0;
-    const size_t start = ((arena_off + a_align - 1) / a_align) * a_align + a_skew * (allocs.size() % 61);
-    if (arena && start + bytes <= arena_bytes) {
-      p = arena + start;
-      arena_off = start + bytes;
-    } else
-#endif
-    {
-      size_t ask = bytes;
-#ifdef PGO_EXPERIMENTS
-      // PGO_ALLOC_POW2=1: sizes rounded up to a power of two (one buddy block per buffer); =2: plus 2 MiB (never one block)
-      static const int pow2 = getenv("PGO_ALLOC_POW2") ? atoi(getenv("PGO_ALLOC_POW2")) : 0;
-      if (pow2 && bytes >= ((size_t)1 << 20)) {
-        size_t r = (size_t)1 << 20;
-        while (r < bytes) r <<= 1;
-        ask = pow2 == 2 ? r + ((size_t)2 << 20) : r;
-      }
-#endif
-      e = hipMalloc(&p, ask);
-      if (e != hipSuccess) return fail(PGO_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-      allocs.push_back(p);
-    }
+    // (one hipMalloc per buffer on purpose: all buffers of a handle carved out of ONE allocation were measured 5-12 % slower in
+    // K1 / K2 / K3 -- DESIGN.md section 8, round 3 (g))
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(PGO_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    allocs.push_back(p);
     device_bytes += (int64_t)bytes;
     e = hipMemsetAsync(p, 0, bytes, stream);
     if (e != hipSuccess) return fail(PGO_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));

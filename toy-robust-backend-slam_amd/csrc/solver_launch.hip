@@ -89,18 +89,8 @@ int pgo_handle::spmv_enqueue(const double* p, double* yout, double* dot_part, in
     case 3: hipLaunchKernelGGL(dev::k_spmv_t<3>, dim3(g_spmv), dim3(dev::WG), 0, stream, A); break;
 #endif
     default:
-#ifdef PGO_EXPERIMENTS
-      if (spmv_pipe && spmv_one_tile && k3_nt == 2) hipLaunchKernelGGL((dev::k_spmv_1<dev::WG, 2>), dim3(g_spmv), dim3(2 * dev::WG), 0, stream, A);
-      else if (spmv_pipe && spmv_one_tile && k3_nt == 4) hipLaunchKernelGGL((dev::k_spmv_1<dev::WG, 4>), dim3(g_spmv), dim3(4 * dev::WG), 0, stream, A);
-      else if (spmv_pipe && spmv_one_tile && k3_tw) {
-        A.tile_desc = k3_desc;
-        A.n_tiles = n_k3;
-        if (k3_tw == 64) hipLaunchKernelGGL(dev::k_spmv_1<64>, dim3(g_spmv), dim3(64), 0, stream, A);
-        else hipLaunchKernelGGL(dev::k_spmv_1<128>, dim3(g_spmv), dim3(128), 0, stream, A);
-      } else
-#endif
-      if (spmv_pipe && spmv_one_tile && S.padded) hipLaunchKernelGGL((dev::k_spmv_1<dev::WG, 1, true>), dim3(g_spmv), dim3(dev::WG), 0, stream, A);
-      else if (spmv_pipe && spmv_one_tile) hipLaunchKernelGGL(dev::k_spmv_1<>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+      if (spmv_pipe && spmv_one_tile && S.padded) hipLaunchKernelGGL(dev::k_spmv_1<true>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
+      else if (spmv_pipe && spmv_one_tile) hipLaunchKernelGGL(dev::k_spmv_1<false>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
       else if (spmv_pipe) hipLaunchKernelGGL(dev::k_spmv_p<dev::PS>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
       else hipLaunchKernelGGL(dev::k_spmv_t<0>, dim3(g_spmv), dim3(dev::WG), 0, stream, A);
   }

@@ -184,9 +184,7 @@ int pgo_handle::pcg(int* iters, double* rel) {
     else PGOC(spmv_enqueue(p_full, ap, part[0], 1, &st->done));
     // p.Ap: every workgroup of the update kernel re-sums the product's partials itself -- up to 2048 of them; more (k_spmv_1:
     // one per tile) are folded to 16 first (k_fold_partials); several ranks: k_finalize + all-reduce
-    int fold_min = 2048;
-    if (const char* fm = PGO_EXP_ENV("PGO_FOLD_MIN")) fold_min = atoi(fm);
-    const bool fold_pap = !multi && n_sp > fold_min;
+    const bool fold_pap = !multi && n_sp > 2048;
     const double* pap = multi ? scal + 6 : (fold_pap ? part[3] : part[0]);
     const int n_pap = multi ? 1 : (fold_pap ? 16 : n_sp);
     if (multi) PGOC(reduce_to_scal({{part[0], n_sp, 0}}, 6));
