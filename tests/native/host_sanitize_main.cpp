@@ -62,6 +62,33 @@ int main(int argc, char** argv) {
             const int r0 = S.tile_row[t], r1 = S.tile_row[t + 1];
             CHECK(r1 > r0 && (S.inc_ptr[r1] - S.inc_ptr[r0] <= pgo::TILE_INC || r1 - r0 == 1));
           }
+          {  // the padded-slot layout of large graphs (pad_tiles_to_slots), on a copy: same incidences, nulls behind them
+            pgo::ShardStructure P = S;
+            const bool plain = pgo::pad_tiles_to_slots(&P);
+            if (plain) {
+              CHECK(P.padded && P.n_inc == (int64_t)P.n_tiles() * pgo::TILE_INC && P.n_inc_real == S.n_inc);
+              CHECK((int64_t)P.inc_ptr.back() == P.n_inc && (int64_t)P.inc_edge.size() == P.n_inc && (int64_t)P.inc_rowoff.size() == P.n_inc);
+              int64_t real = 0;
+              for (int t = 0; t < P.n_tiles(); ++t) {
+                const int r0 = P.tile_row[t], r1 = P.tile_row[t + 1];
+                CHECK(P.inc_ptr[r0] == t * pgo::TILE_INC);
+                for (int r = r0; r < r1; ++r) {
+                  const int nreal = S.inc_ptr[r + 1] - S.inc_ptr[r];
+                  for (int k = 0; k < nreal; ++k) {   // the row's real incidences, in order, at the start of its slot range
+                    CHECK(P.inc_edge[P.inc_ptr[r] + k] == S.inc_edge[S.inc_ptr[r] + k] && P.inc_col[P.inc_ptr[r] + k] == S.inc_col[S.inc_ptr[r] + k]);
+                    CHECK(P.inc_rowoff[P.inc_ptr[r] + k] == r - r0);
+                  }
+                  real += nreal;
+                  for (int q = P.inc_ptr[r] + nreal; q < P.inc_ptr[r + 1]; ++q)   // nulls: only behind a tile's last row
+                    CHECK(r == r1 - 1 && P.inc_edge[q] == -1 && P.inc_col[q] == P.lo + r && P.inc_rowoff[q] == r - r0);
+                }
+              }
+              CHECK(real == S.n_inc);
+              CHECK(!pgo::pad_tiles_to_slots(&P));   // idempotent: a padded structure is left alone
+            } else {
+              CHECK(!P.padded && P.n_inc == S.n_inc);
+            }
+          }
           for (int s = 0; s < world; ++s) {
             snd_total[rank] += S.halo_send_off[s + 1] - S.halo_send_off[s];
             rcv_total[rank] += S.halo_recv_off[s + 1] - S.halo_recv_off[s];
