@@ -250,6 +250,24 @@ def test_error_strings(pgo):
     assert b"unknown" in L.pgo_strerror(-99)
 
 
+def test_debug_knobs_are_named_and_documented(pgo):
+    """pgo_debug_set_knob: every test hook the library knows is documented in include/pgo.h, an unknown name is an error
+    (a typo in a test must not silently leave the default in place), and setting a hook back to -1 is accepted"""
+    text = open(os.path.join(ROOT, "include", "pgo.h")).read()
+    documented = re.findall(r'^ \*   "([a-z_0-9]+)"', text, flags=re.M)
+    assert {"spmv_pipe", "fused_p", "direct_fail_at", "direct_setup_fail", "single_reduction", "verify_residual", "shm_timeout_s",
+            "pad_tiles"} <= set(documented)
+    for name in documented:
+        pgo.set_knob(name, -1)
+    with pytest.raises(pgo.PgoError) as e:
+        pgo.set_knob("no_such_knob", 1)
+    assert e.value.status == -1
+    # ... and every name in the library's table is documented: the table is the one string list next to g_knobs
+    src = open(os.path.join(ROOT, "toy-robust-backend-slam_amd", "csrc", "solver_abi.hip")).read()
+    table = re.search(r"Knob g_knobs\[\] = \{(.*?)\};", src, flags=re.S).group(1)
+    assert set(re.findall(r'\{"([a-z_0-9]+)"', table)) == set(documented)
+
+
 def test_solver_fails_loudly_without_gpu(pgo):
     """no CPU fallback: without a device the product path refuses to run"""
     import torch
